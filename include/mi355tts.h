@@ -1,0 +1,158 @@
+/* mi355tts — C ABI of the MI355X-native Larynx hot path
+ * (phoneme ids -> GlowTTS -> mel transform -> HiFi-GAN -> waveform).
+ *
+ * This is what a Larynx maintainer binds (ctypes) behind the
+ * reference's own model interface.  Every entry point names the reference
+ * interface it replaces (paths relative to rhasspy/larynx v1.1.0):
+ *
+ *   larynx/constants.py:62-72   TextToSpeechModel.phonemes_to_mels
+ *   larynx/constants.py:90-100  VocoderModel.mels_to_audio
+ *   larynx/glow_tts.py:109-170  GlowTextToSpeech.phonemes_to_mels  (ORT feed dict :161-168)
+ *   larynx/hifi_gan.py:130-169  HiFiGanVocoder.mels_to_audio
+ *   larynx/__init__.py:214-285  _sentence_task (mel transforms :242-249)
+ *   larynx/audio.py:83-125      AudioSettings.denormalize/db_to_amp/
+ *                               dynamic_range_compression, audio_float_to_int16
+ *   glow_tts/checkpoint.py:26-68, hifi_gan/checkpoint.py:36-70   load_checkpoint
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative mi355tts_status, never throws or aborts;
+ * mi355tts_last_error() gives the calling thread's last message.  All entry
+ * points are re-entrant: many host threads may call into one context
+ * concurrently (the reference calls its models from a ThreadPoolExecutor,
+ * larynx/__init__.py:146); each call runs on its own HIP stream + workspace.
+ * Tensors are row-major, channel-major like the reference's `[1, 80, F]` mels:
+ * [batch][channel][time], time fastest.
+ */
+#ifndef MI355TTS_H
+#define MI355TTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355TTS_ABI_VERSION 1
+
+typedef enum {
+  MI355TTS_OK = 0,
+  MI355TTS_ERR_INVALID = -1,   /* bad argument / unsupported hyper-parameter  */
+  MI355TTS_ERR_HIP = -2,       /* a HIP runtime call failed (message has it)   */
+  MI355TTS_ERR_NOMEM = -3,
+  MI355TTS_ERR_TOO_SMALL = -4, /* caller-provided buffer too small             */
+  MI355TTS_ERR_NO_MODEL = -5
+} mi355tts_status;
+
+typedef struct mi355tts_ctx mi355tts_ctx; /* one per process per GPU              */
+typedef struct mi355tts_mel mi355tts_mel; /* device-resident mel batch             */
+
+/* glow_tts/config.py:36-62 (ModelConfig) + audio.mel_channels */
+typedef struct {
+  int32_t num_symbols, hidden_channels, filter_channels, filter_channels_dp;
+  int32_t kernel_size, n_blocks_dec, n_layers_enc, n_heads;
+  int32_t dilation_rate, kernel_size_dec, n_block_layers, n_sqz;
+  int32_t prenet, window_size, n_split, mel_channels;
+  int32_t prenet_kernel_size, prenet_layers; /* glow_tts/models.py:96-97 (5, 3) */
+} mi355tts_glow_hparams;
+
+/* hifi_gan/config.py:29-41 (ModelConfig) */
+#define MI355TTS_MAX_STAGES 8
+typedef struct {
+  int32_t resblock_type; /* 1 = ResBlock1, 2 = ResBlock2                       */
+  int32_t num_upsamples;
+  int32_t upsample_rates[MI355TTS_MAX_STAGES];
+  int32_t upsample_kernel_sizes[MI355TTS_MAX_STAGES];
+  int32_t upsample_initial_channel;
+  int32_t num_kernels;
+  int32_t resblock_kernel_sizes[MI355TTS_MAX_STAGES];
+  int32_t num_dilations;
+  int32_t resblock_dilations[MI355TTS_MAX_STAGES][MI355TTS_MAX_STAGES];
+  int32_t num_mels;
+} mi355tts_hifigan_hparams;
+
+/* larynx/audio.py:26-50 (the fields the mel transforms read) */
+typedef struct {
+  int32_t signal_norm, symmetric_norm, clip_norm;
+  int32_t convert_db_to_amp, do_dynamic_range_compression;
+  float min_level_db, max_norm, ref_level_db, spec_gain;
+} mi355tts_audio_settings;
+
+/* flags for the inference calls */
+#define MI355TTS_IN_DEVICE 1u  /* ids / noise / mel input pointers are device memory */
+#define MI355TTS_OUT_DEVICE 2u /* waveform output pointers are device memory          */
+
+int mi355tts_abi_version(void);
+const char* mi355tts_last_error(void);
+
+int mi355tts_create(int device, mi355tts_ctx** out);
+void mi355tts_destroy(mi355tts_ctx* ctx);
+
+/* ---- weights ---------------------------------------------------------------
+ * A model is loaded from ONE flat fp32 blob: the reference checkpoint's tensors
+ * (weight-norm folded, `remove_weight_norm` / `store_inverse` semantics) laid end
+ * to end in the order the manifest enumerates.  `*_manifest` returns the i-th
+ * tensor's reference state-dict name and element count (1 = past the end), so
+ * the host-side converter never hard-codes the order.  `on_device` != 0 means
+ * `blob` is device memory (e.g. the receive buffer of an RCCL broadcast).
+ * Replaces load_checkpoint + .eval() in larynx/glow_tts.py:66-95 and
+ * larynx/hifi_gan.py:71-100. */
+int mi355tts_glow_manifest(const mi355tts_glow_hparams* hp, int index, char* name, int name_cap, int64_t* numel);
+int mi355tts_hifigan_manifest(const mi355tts_hifigan_hparams* hp, int index, char* name, int name_cap, int64_t* numel);
+int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams* hp, const float* blob, int64_t numel,
+                       int on_device, int* model_out);
+int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_hparams* hp, const float* blob, int64_t numel,
+                          int on_device, int* model_out);
+int mi355tts_unload(mi355tts_ctx* ctx, int model);
+
+/* ---- GlowTTS: replaces GlowTextToSpeech.phonemes_to_mels --------------------
+ * ids [B][ids_ld] int64 (row b valid for id_lens[b] entries; the reference's
+ * "input" / "input_lengths"), scales as in the reference's "scales" input.
+ * noise: optional N(0,1) tensor [B][mel_channels][noise_ld] standing in for
+ * torch.randn_like (glow_tts/models.py:348) — parity mode; NULL draws from a
+ * counter-based generator keyed by `seed`.  `audio` (optional) additionally
+ * produces the vocoder-input mel (the three numpy transforms of _sentence_task).
+ * The frame count is data dependent; the result stays on the device. */
+int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                        float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                        const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);
+
+int mi355tts_mel_batch(const mi355tts_mel* mel);
+int mi355tts_mel_channels(const mi355tts_mel* mel);
+int mi355tts_mel_max_frames(const mi355tts_mel* mel);
+int mi355tts_mel_frames(const mi355tts_mel* mel, int32_t* frames /* [B] */);
+/* which: 0 = raw GlowTTS output, 1 = vocoder input.  dst is host [B][M][ld], ld >= max_frames */
+int mi355tts_mel_copy(const mi355tts_mel* mel, int which, float* dst, int ld);
+void mi355tts_mel_free(mi355tts_mel* mel);
+/* Wrap a host (or device) mel [B][M][ld]; apply the mel transforms iff `audio` != NULL. */
+int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, const int32_t* frames, int B, int M, int ld,
+                             const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);
+
+/* ---- HiFi-GAN: replaces HiFiGanVocoder.mels_to_audio ------------------------
+ * Consumes the vocoder-input mel; writes per row frames[b]*hop samples (tail up
+ * to wav_ld zero-filled).  wav_f32 (optional) is the generator output before
+ * audio_float_to_int16; wav_i16 (optional) after it.  wav_ld >= max_frames*hop. */
+int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder);
+int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float* wav_f32, int16_t* wav_i16,
+                           int64_t wav_ld, uint32_t flags);
+
+/* ---- single operators (kernel-level parity tests, drop-in conv) ------------- */
+/* y[B][Cout][L] = act_out(bias + conv1d(lrelu_slope(x[B][Cin][L]), w[Cout][Cin][K], dilation, "same" padding)) */
+int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const int32_t* lens, const float* w,
+                       const float* bias, int Cout, int K, int dilation, float in_slope, int out_act, float* y);
+/* y[B][Cout][L*stride] = bias + conv_transpose1d(lrelu_slope(x), w[Cin][Cout][K], stride, padding=(K-stride)/2) */
+int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const float* w,
+                                 const float* bias, int Cout, int K, int stride, float in_slope, float* y);
+
+/* ---- measurement -------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the
+ * call's own stream and accumulated per kernel class.  `mi355tts_profile_json`
+ * writes {"class": {"launches": n, "ms": t, "flop": f}, ...}. */
+int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
+int mi355tts_profile_reset(mi355tts_ctx* ctx);
+int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355TTS_H */

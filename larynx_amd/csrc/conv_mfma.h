@@ -1,0 +1,284 @@
+// conv1d / conv-transpose1d / 1x1 as an implicit GEMM on the CDNA4 f32 matrix
+// cores (v_mfma_f32_32x32x2_f32: exact f32, bit-equal to an fmaf chain).
+//
+//   y[co][t] = epi( bias[co] + sum_{ci,k} W[co][ci][k] * act(x[ci][t + k*dil - pad]) )
+//
+// GEMM view: M = output channels (A = weights, pre-packed in MFMA fragment order
+// and streamed straight from L2 into VGPRs, 16 B per lane per load),
+// N = time (B = activations, staged through LDS with the input activation applied
+// once per element, halo included), K-dim = (ci, tap).
+//
+// One workgroup = 4 waves = (MB*32) output rows x (4*NB*32) time columns; each
+// wave owns MB x NB MFMA blocks of 32x32 (16 accumulator VGPRs each).
+//
+// This one kernel covers every dense contraction on the Larynx hot path
+// (reference ops): HiFi-GAN conv_pre / ResBlock convs / conv_post
+// (hifi_gan/models.py:91-98,136-141,186-200), the transposed-conv upsampler in
+// polyphase form (:189-190), and the GlowTTS prenet / FFN / 1x1 / WaveNet convs
+// (glow_tts/layers.py:73-80,138-162; attentions.py:119-142,375-383).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi355tts {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum ConvEpilogue {
+  EPI_LINEAR = 0,    // y = [y +] alpha * (acc + bias [+ res]) ; optional row split into (y, y2)
+  EPI_GATE = 1,      // y[c] = tanh(acc[2p]) * sigmoid(acc[2p+1])      (glow_tts/utils.py:31-38)
+  EPI_COUPLING = 2,  // y[c] = (res[c] - acc_m) * exp(-acc_logs)        (attentions.py:135-136)
+  EPI_UPSAMPLE = 3,  // polyphase ConvTranspose1d scatter: row = co*u + r -> y[co][q*u + r - p]
+};
+
+enum OutAct { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+struct ConvArgs {
+  // input activations [B][Cin][x_ld]
+  const float* x;
+  long long x_bs;
+  int x_ld;
+  // valid input length per batch row: in_len ? in_len[b] * in_mul : in_const
+  const int* in_len;
+  int in_mul;
+  int in_const;
+  // packed weights (see pack_conv_weights in weights_pack.h) and packed bias
+  const float* w;
+  const float* bias;
+  int noct;  // ceil(Cin / 8)
+  int Cin;
+  int rows;  // number of valid virtual output rows
+  int dil;
+  int pad;
+  float in_slope;  // leaky-relu slope applied to x on load (1.0 = identity)
+  // output (rows < split) and second output (rows >= split, row index re-based)
+  float* y;
+  long long y_bs;
+  int y_ld;
+  const float* res;  // optional residual, same geometry as y
+  float* y2;
+  long long y2_bs;
+  int y2_ld;
+  int split;
+  int accum;   // y  += instead of y  =
+  int accum2;  // y2 += instead of y2 =
+  float alpha;
+  int out_act;
+  // valid output length per batch row: out_len ? out_len[b] * out_mul : out_const
+  const int* out_len;
+  int out_mul;
+  int out_const;
+  // EPI_UPSAMPLE: stride and crop of the transposed conv; EPI_GATE/COUPLING: channels
+  int up;
+  int up_pad;
+  int half;
+};
+
+template <int K, int CI_C, int MB, int NB, int HALO, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int T_T = 4 * NB * 32;  // time columns per workgroup
+  constexpr int XW = T_T + HALO;    // LDS row stride (floats)
+  constexpr int NR = CI_C / 4;      // staging rows per thread
+  constexpr int NC = (XW + 63) / 64;
+  constexpr int S = (CI_C / 8) * K;  // k-steps (8 channels x 1 tap) per staged chunk
+  static_assert(CI_C % 8 == 0, "CI_C must be a multiple of 8");
+
+  __shared__ float xs[2 * CI_C * XW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tx = tid & 63;
+  const int ty = tid >> 6;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * T_T;
+  const int mt0 = blockIdx.y * MB;
+
+  const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
+  const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
+  // extent of the GEMM's N axis for this batch row
+  const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;
+  if (t0 >= n_len) return;  // uniform per workgroup
+
+  const int roww = T_T + (K - 1) * a.dil;  // staged columns actually used
+  const float slope = a.in_slope;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int nchunks = (a.noct * 8 + CI_C - 1) / CI_C;
+
+  float pre[NR * NC];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int ci = chunk * CI_C + ty + 4 * i;
+      const float* xr = xb + (long long)ci * a.x_ld;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int cc = tx + 64 * j;
+        const int ti = t0 - a.pad + cc;
+        float v = 0.f;
+        if (cc < roww && ci < a.Cin && ti >= 0 && ti < Lin) v = xr[ti];
+        v = v > 0.f ? v : v * slope;
+        pre[i * NC + j] = v;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* dst = xs + buf * (CI_C * XW);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int cc = tx + 64 * j;
+        if (cc < XW) dst[(ty + 4 * i) * XW + cc] = pre[i * NC + j];
+      }
+    }
+  };
+
+  floatx16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // A-fragment stream of m-tile mt: float4 index ((mt*noct + oct)*K + k)*64 + lane
+  const float4* wq[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    wq[mb] = reinterpret_cast<const float4*>(a.w) + (long long)(mt0 + mb) * a.noct * K * 64 + lane;
+  const int total_steps = a.noct * K;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  float4 a_cur[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wq[mb][0];
+
+  const int b_off = (lane >> 5) * XW + wave * (NB * 32) + (lane & 31);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < nchunks) gload(chunk + 1);
+    const float* xt = xs + buf * (CI_C * XW) + b_off;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int gs = chunk * S + s;
+      if (gs < total_steps) {  // uniform; false only in a ragged last chunk
+        const int o = s / K;
+        const int k = s - o * K;
+        float4 a_nxt[MB];
+        const int gn = (gs + 1 < total_steps) ? gs + 1 : gs;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wq[mb][(long long)gn * 64];
+        const float* bp = xt + (o * 8) * XW + k * a.dil;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float bv[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[(2 * j) * XW + nb * 32];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const float av = (j == 0) ? a_cur[mb].x : (j == 1) ? a_cur[mb].y : (j == 2) ? a_cur[mb].z : a_cur[mb].w;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nb], acc[mb][nb], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+      }
+    }
+    if (chunk + 1 < nchunks) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int col = lane & 31;
+  const int rbase = 4 * (lane >> 5);
+
+  if constexpr (EPI == EPI_LINEAR) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int t = t0 + (wave * NB + nb) * 32 + col;
+        if (t >= Lout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+          if (row >= a.rows) continue;
+          float v = acc[mb][nb][r];
+          if (a.bias) v += a.bias[row];
+          if (row < a.split) {
+            const long long o = (long long)b * a.y_bs + (long long)row * a.y_ld + t;
+            if (a.res) v += a.res[o];
+            v *= a.alpha;
+            if (a.accum) v += a.y[o];
+            if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (a.out_act == ACT_TANH) v = tanhf(v);
+            a.y[o] = v;
+          } else {
+            const long long o = (long long)b * a.y2_bs + (long long)(row - a.split) * a.y2_ld + t;
+            if (a.accum2) v += a.y2[o];
+            a.y2[o] = v;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_GATE || EPI == EPI_COUPLING) {
+    static_assert(MB == 2, "paired epilogues need MB == 2");
+    // virtual tile pair p = blockIdx.y: block 0 holds rows c = p*32 + i of the
+    // first half (tanh / m), block 1 the matching rows of the second half.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int t = t0 + (wave * NB + nb) * 32 + col;
+      if (t >= Lout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + rbase;
+        const int c = blockIdx.y * 32 + i;
+        if (c >= a.half) continue;
+        float v0 = acc[0][nb][r];
+        float v1 = acc[MB - 1][nb][r];
+        if (a.bias) {
+          v0 += a.bias[mt0 * 32 + i];
+          v1 += a.bias[(mt0 + 1) * 32 + i];
+        }
+        const long long o = (long long)b * a.y_bs + (long long)c * a.y_ld + t;
+        float out;
+        if constexpr (EPI == EPI_GATE) {
+          out = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
+        } else {
+          out = (a.res[o] - v0) * expf(-v1);
+        }
+        a.y[o] = out;
+      }
+    }
+  } else {  // EPI_UPSAMPLE
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int q = t0 + (wave * NB + nb) * 32 + col;
+        if (q >= n_len) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+          if (row >= a.rows) continue;
+          const int co = row / a.up;
+          const int ph = row - co * a.up;
+          const int n = q * a.up + ph - a.up_pad;
+          if (n < 0 || n >= Lout) continue;
+          float v = acc[mb][nb][r];
+          if (a.bias) v += a.bias[row];
+          a.y[(long long)b * a.y_bs + (long long)co * a.y_ld + n] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mi355tts

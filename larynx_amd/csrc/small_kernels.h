@@ -1,0 +1,396 @@
+// The non-GEMM kernels of the Larynx hot path: gathers, per-column reductions
+// (LayerNorm, softmax), the duration -> frame expansion, the invertible 4x4
+// mixing + ActNorm, the mel transform and the int16 conversion.  All are
+// HBM/L2-bound byte shufflers: one pass, coalesced along time, wave64
+// reductions through __shfl_xor.
+//
+// Tensors are [B][C][ld] with time fastest; `len[b]` is the valid length of row
+// b and everything beyond it is never read (readers mask) — that reproduces the
+// reference's `* x_mask` (glow_tts/models.py:118-140) and gives the vocoder the
+// per-utterance zero padding the un-batched reference has.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355tts {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// G1: x[b][c][t] = emb[ids[b][t]][c] * sqrt(H)           (glow_tts/models.py:119-120)
+__global__ void embed_kernel(const long long* ids, int ids_ld, const int* len, const float* emb, int V, int H,
+                             float scale, float* x, long long x_bs, int x_ld) {
+  const int b = blockIdx.z;
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int c0 = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (t >= len[b]) return;
+  long long id = ids[(long long)b * ids_ld + t];
+  if (id < 0) id = 0;
+  if (id >= V) id = V - 1;
+  for (int c = c0; c < H; c += 4 * gridDim.y) x[(long long)b * x_bs + (long long)c * x_ld + t] = emb[id * H + c] * scale;
+}
+
+// LayerNorm over channels of (x [+ res]) per time column (glow_tts/layers.py:19-28),
+// eps inside the sqrt, biased variance.  pre_relu: DurationPredictor order
+// conv -> ReLU -> LN (models.py:39-49); post_relu: prenet order conv -> LN -> ReLU
+// (layers.py:73-80).  Block = 64 columns x 4 channel groups.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* res, const float* gamma,
+                                                        const float* beta, float* y, int C, long long bs, int ld,
+                                                        const int* len, int pre_relu, int post_relu, float eps) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y;
+  const int tl = threadIdx.x & 63;
+  const int g = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const bool valid = t < len[b];
+  const float* xb = x + (long long)b * bs + t;
+  const float* rb = res ? res + (long long)b * bs + t : nullptr;
+  float s = 0.f;
+  if (valid)
+    for (int c = g; c < C; c += 4) {
+      float v = xb[(long long)c * ld];
+      if (rb) v += rb[(long long)c * ld];
+      if (pre_relu) v = fmaxf(v, 0.f);
+      s += v;
+    }
+  red[g][tl] = s;
+  __syncthreads();
+  const float mean = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  __syncthreads();
+  float q = 0.f;
+  if (valid)
+    for (int c = g; c < C; c += 4) {
+      float v = xb[(long long)c * ld];
+      if (rb) v += rb[(long long)c * ld];
+      if (pre_relu) v = fmaxf(v, 0.f);
+      const float d = v - mean;
+      q += d * d;
+    }
+  red[g][tl] = q;
+  __syncthreads();
+  const float var = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
+  const float rstd = rsqrtf(var + eps);
+  if (!valid) return;
+  float* yb = y + (long long)b * bs + t;
+  for (int c = g; c < C; c += 4) {
+    float v = xb[(long long)c * ld];
+    if (rb) v += rb[(long long)c * ld];
+    if (pre_relu) v = fmaxf(v, 0.f);
+    float o = (v - mean) * rstd * gamma[c] + beta[c];
+    if (post_relu) o = fmaxf(o, 0.f);
+    yb[(long long)c * ld] = o;
+  }
+}
+
+// G4: windowed relative-position self-attention (glow_tts/attentions.py:214-264).
+// qkv is [B][3H][ld] (q rows 0..H, k rows H..2H, v rows 2H..3H), head h uses
+// channels h*dk..(h+1)*dk.  One wave per query row i, 4 rows per workgroup:
+//   s[j] = (q_i.k_j + [|j-i|<=w] q_i.Ek[j-i+w]) / sqrt(dk);  p = softmax_j(s)
+//   o[c] = sum_j p[j] v[c][j] + sum_{|r-w|<=w} p[i+r-w] Ev[r][c]
+// Keys j >= len[b] carry exactly zero weight (the reference fills -1e4, whose
+// softmax weight underflows to 0 in fp32).  The band is evaluated directly; the
+// reference's pad/reshape skewing (attentions.py:284-335) is never materialised.
+constexpr int ATT_ROWS = 4;
+constexpr int ATT_MAXW = 16;   // max 2*window+1
+constexpr int ATT_JCH = 64;    // keys per staged V chunk
+constexpr int ATT_MAXDK = 128;
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
+                                                        int nheads, int window, const float* ek, const float* ev,
+                                                        float* out, long long out_bs, int out_ld, float* scores_ws,
+                                                        int ws_ld) {
+  __shared__ float rel[ATT_ROWS][ATT_MAXW];
+  __shared__ float vs[ATT_MAXDK][ATT_JCH + 1];
+  __shared__ float ps[ATT_ROWS][ATT_JCH];
+  const int b = blockIdx.z;
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int P = len[b];
+  const int i = blockIdx.x * ATT_ROWS + wave;
+  const int dk = H / nheads;
+  const int nrel = 2 * window + 1;
+  const float scale = rsqrtf((float)dk);
+  const bool row_ok = i < P;
+  const float* q = qkv + (long long)b * bs + (long long)(h * dk) * ld;
+  const float* k = q + (long long)H * ld;
+  const float* v = k + (long long)H * ld;
+  // per-(b,h,row) scratch for the score row (P can exceed what fits in LDS)
+  float* srow = scores_ws + ((long long)(b * nheads + h) * gridDim.x * ATT_ROWS + (blockIdx.x * ATT_ROWS + wave)) * ws_ld;
+
+  // relative-key logits for the 2w+1 band
+  for (int r = 0; r < nrel; ++r) {
+    float part = 0.f;
+    if (row_ok)
+      for (int c = lane; c < dk; c += 64) part += q[(long long)c * ld + i] * ek[r * dk + c];
+    part = wave_sum(part);
+    if (lane == 0) rel[wave][r] = part;
+  }
+  __syncthreads();
+
+  // scores and running max
+  float mx = -3.0e38f;
+  if (row_ok) {
+    for (int j = lane; j < P; j += 64) {
+      float s = 0.f;
+      for (int c = 0; c < dk; ++c) s += q[(long long)c * ld + i] * k[(long long)c * ld + j];
+      const int r = j - i + window;
+      float sl = 0.f;
+      if (r >= 0 && r < nrel) sl = rel[wave][r];
+      s = s * scale + sl * scale;
+      srow[j] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  float den = 0.f;
+  if (row_ok) {
+    for (int j = lane; j < P; j += 64) {
+      const float e = expf(srow[j] - mx);
+      srow[j] = e;
+      den += e;
+    }
+  }
+  den = wave_sum(den);
+  const float inv = row_ok ? 1.0f / den : 0.f;
+
+  // o[c] accumulation: lanes over channels, V staged chunk-wise through LDS
+  float acc0 = 0.f, acc1 = 0.f;  // channels lane and lane+64
+  for (int j0 = 0; j0 < P; j0 += ATT_JCH) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < dk * ATT_JCH; e += 256) {
+      const int c = e / ATT_JCH, jj = e - c * ATT_JCH;
+      vs[c][jj] = (j0 + jj < P) ? v[(long long)c * ld + j0 + jj] : 0.f;
+    }
+    if (lane < ATT_JCH) ps[wave][lane] = (row_ok && j0 + lane < P) ? srow[j0 + lane] * inv : 0.f;
+    __syncthreads();
+    const int jn = (P - j0 < ATT_JCH) ? P - j0 : ATT_JCH;
+    for (int jj = 0; jj < jn; ++jj) {
+      const float p = ps[wave][jj];
+      if (lane < dk) acc0 += p * vs[lane][jj];
+      if (lane + 64 < dk) acc1 += p * vs[lane + 64][jj];
+    }
+  }
+  if (!row_ok) return;
+  // relative values on the band
+  for (int r = 0; r < nrel; ++r) {
+    const int j = i + r - window;
+    if (j < 0 || j >= P) continue;
+    const float p = srow[j] * inv;
+    if (lane < dk) acc0 += p * ev[r * dk + lane];
+    if (lane + 64 < dk) acc1 += p * ev[r * dk + lane + 64];
+  }
+  float* ob = out + (long long)b * out_bs + (long long)(h * dk) * out_ld + i;
+  if (lane < dk) ob[(long long)lane * out_ld] = acc0;
+  if (lane + 64 < dk) ob[(long long)(lane + 64) * out_ld] = acc1;
+}
+
+// G9a: durations.  w = exp(logw)*length_scale, w_ceil = ceil(w); cum = inclusive
+// cumsum; frames = max(sum,1) truncated to a multiple of n_sqz
+// (glow_tts/models.py:323-336).  One workgroup per batch row.
+__global__ void duration_kernel(const float* logw, long long bs, const int* len, float length_scale, int n_sqz,
+                                int* cum, int cum_ld, int* frames, int max_frames_cap) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int P = len[b];
+  float total = 0.f;
+  for (int t = 0; t < P; ++t) {
+    const float w = expf(logw[(long long)b * bs + t]) * length_scale;
+    total += ceilf(w);
+    cum[(long long)b * cum_ld + t] = (int)total;
+  }
+  int y = (int)fmaxf(total, 1.0f);
+  y = (y / n_sqz) * n_sqz;
+  if (y > max_frames_cap) y = (max_frames_cap / n_sqz) * n_sqz;
+  frames[b] = y;
+}
+
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+// counter-based N(0,1): two hashed uniforms -> Box-Muller
+__device__ __forceinline__ float gauss_noise(uint64_t seed, uint32_t b, uint32_t c, uint32_t t) {
+  uint32_t k = pcg_hash((uint32_t)seed ^ pcg_hash((uint32_t)(seed >> 32) + 0x9e3779b9u));
+  uint32_t x = pcg_hash(k ^ pcg_hash(b * 0x85ebca6bu + c) ^ (t * 0xc2b2ae35u));
+  uint32_t y = pcg_hash(x ^ 0x27d4eb2fu);
+  const float u1 = ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(y >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+
+// G9b+G10+G11: frame j of row b repeats id idx(j) = #{t : cum[t] <= j}
+// (glow_tts/utils.py:99-115 `generate_path`, never materialised as a matrix);
+// z = x_m[:, idx] + noise * noise_scale (models.py:348), written directly in the
+// squeezed layout z_sqz[s*M + c][j/n] (utils.py:135-147).
+__global__ void expand_noise_squeeze_kernel(const float* xm, long long xm_bs, int xm_ld, const int* len,
+                                            const int* cum, int cum_ld, const int* frames, const float* noise,
+                                            long long noise_bs, int noise_ld, float noise_scale, uint64_t seed,
+                                            int M, int n_sqz, float* z, long long z_bs, int z_ld) {
+  const int b = blockIdx.z;
+  const int F = frames[b];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= F) return;
+  const int P = len[b];
+  const int* cb = cum + (long long)b * cum_ld;
+  int lo = 0, hi = P;  // first t with cum[t] > j
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cb[mid] <= j) lo = mid + 1; else hi = mid;
+  }
+  const int id = lo < P ? lo : P - 1;
+  const int s = j % n_sqz, j2 = j / n_sqz;
+  for (int c = blockIdx.y; c < M; c += gridDim.y) {
+    float v = xm[(long long)b * xm_bs + (long long)c * xm_ld + id];
+    if (noise_scale != 0.f) {
+      const float nz = noise ? noise[(long long)b * noise_bs + (long long)c * noise_ld + j]
+                             : gauss_noise(seed, (uint32_t)b, (uint32_t)c, (uint32_t)j);
+      v += nz * noise_scale;
+    }
+    z[(long long)b * z_bs + (long long)(s * M + c) * z_ld + j2] = v;
+  }
+}
+
+// G12b+G12a: InvConvNear reverse (pre-inverted 4x4, glow_tts/layers.py:238-272)
+// followed by ActNorm reverse (layers.py:192-194), in place on x[B][C][ld].
+// Group k mixes channels {a*C/2 + k*(ns/2) + s}, n = a*(ns/2)+s.
+__global__ void invconv_actnorm_kernel(float* x, long long bs, int ld, const int* frames, int div, int C, int ns,
+                                       const float* winv, const float* an_bias, const float* an_scale) {
+  const int b = blockIdx.z;
+  const int T = frames[b] / div;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int groups = C / ns;
+  const int hs = ns / 2;
+  float* xb = x + (long long)b * bs + t;
+  for (int k = blockIdx.y; k < groups; k += gridDim.y) {
+    float in[8], o[8];
+    for (int n = 0; n < ns; ++n) {
+      const int a = n / hs, s = n - a * hs;
+      in[n] = xb[(long long)(a * (C / 2) + k * hs + s) * ld];
+    }
+    for (int m = 0; m < ns; ++m) {
+      float acc = 0.f;
+      for (int n = 0; n < ns; ++n) acc += winv[m * ns + n] * in[n];
+      o[m] = acc;
+    }
+    for (int m = 0; m < ns; ++m) {
+      const int a = m / hs, s = m - a * hs;
+      const int c = a * (C / 2) + k * hs + s;
+      xb[(long long)c * ld] = (o[m] - an_bias[c]) * an_scale[c];
+    }
+  }
+}
+
+struct MelTransform {
+  int signal_norm, symmetric_norm, clip_norm, convert_db_to_amp, do_drc;
+  float min_level_db, max_norm, ref_level_db, spec_gain;
+};
+
+// The numpy mel transforms of `_sentence_task` (larynx/__init__.py:242-249 ->
+// larynx/audio.py:83-108), kept in the reference's pow -> log form because of
+// the 1e-5 clamp.
+__device__ __forceinline__ float mel_transform(float v, const MelTransform& m) {
+  if (m.signal_norm) {
+    if (m.symmetric_norm) {
+      if (m.clip_norm) v = fminf(fmaxf(v, -m.max_norm), m.max_norm);
+      v = ((v + m.max_norm) * -m.min_level_db / (2.0f * m.max_norm)) + m.min_level_db;
+    } else {
+      if (m.clip_norm) v = fminf(fmaxf(v, 0.f), m.max_norm);
+      v = (v * -m.min_level_db / m.max_norm) + m.min_level_db;
+    }
+    v += m.ref_level_db;
+  }
+  if (m.convert_db_to_amp) v = powf(10.0f, v / m.spec_gain);
+  if (m.do_drc) v = logf(fmaxf(v, 1e-5f));
+  return v;
+}
+
+// G13 + M1: unsqueeze [C][F/n] -> [M][F] (glow_tts/utils.py:150-160), write the
+// raw mel (the GlowTTS output the parity check is defined on) and the vocoder
+// input; the padded tail [F_b, ld) of both is zero-filled.
+__global__ void mel_finalize_kernel(const float* x, long long x_bs, int x_ld, const int* frames, int M, int n_sqz,
+                                    float* mel, float* mel_voc, long long mel_bs, int mel_ld, MelTransform mt,
+                                    int apply) {
+  const int b = blockIdx.z;
+  const int F = frames[b];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= mel_ld) return;
+  const int s = j % n_sqz, j2 = j / n_sqz;
+  for (int c = blockIdx.y; c < M; c += gridDim.y) {
+    float v = 0.f, u = 0.f;
+    if (j < F) {
+      v = x[(long long)b * x_bs + (long long)(s * M + c) * x_ld + j2];
+      u = apply ? mel_transform(v, mt) : v;
+    }
+    const long long o = (long long)b * mel_bs + (long long)c * mel_ld + j;
+    mel[o] = v;
+    mel_voc[o] = u;
+  }
+}
+
+// M1 alone, for mels that arrive from the host (drop-in `mels_to_audio`).
+__global__ void mel_transform_kernel(const float* in, float* out, long long n, MelTransform mt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mel_transform(in[i], mt);
+}
+
+// H5 pass 1: per-row max |a| as uint bits (monotone for non-negative floats).
+__global__ void absmax_kernel(const float* wav, long long bs, const int* frames, int hop, unsigned* peak_bits) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long long N = (long long)frames[b] * hop;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(wav[(long long)b * bs + i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = red[0];
+    for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) r = fmaxf(r, red[w]);
+    atomicMax(&peak_bits[b], __float_as_uint(r));
+  }
+}
+
+// H5 pass 2: `audio_float_to_int16` (larynx/audio.py:118-125): a * 32767/max(0.01,peak),
+// clip, truncate toward zero; the padded tail is zero.
+__global__ void to_int16_kernel(const float* wav, long long bs, const int* frames, int hop, const unsigned* peak_bits,
+                                short* out, long long out_bs, long long out_ld) {
+  const int b = blockIdx.y;
+  const long long N = (long long)frames[b] * hop;
+  const float peak = fmaxf(0.01f, __uint_as_float(peak_bits[b]));
+  const float g = 32767.0f / peak;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < out_ld; i += (long long)gridDim.x * blockDim.x) {
+    short s = 0;
+    if (i < N) {
+      float v = wav[(long long)b * bs + i] * g;
+      v = fminf(fmaxf(v, -32767.0f), 32767.0f);
+      s = (short)(int)v;
+    }
+    out[(long long)b * out_bs + i] = s;
+  }
+}
+
+__global__ void zero_tail_kernel(float* wav, long long bs, long long ld, const int* frames, int hop) {
+  const int b = blockIdx.y;
+  const long long N = (long long)frames[b] * hop;
+  for (long long i = N + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += (long long)gridDim.x * blockDim.x)
+    wav[(long long)b * bs + i] = 0.f;
+}
+
+__global__ void fill_int_kernel(int* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace mi355tts

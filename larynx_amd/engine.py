@@ -1,0 +1,240 @@
+"""One `Engine` per process per GPU: owns the C-ABI context, the resident models
+and the thin numpy marshalling around the inference entry points."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import threading
+import typing
+
+import numpy as np
+
+from . import ffi
+from .hparams import GlowHParams, HifiGanHParams
+from .weights import build_blob
+
+
+class MelBatch:
+    """Device-resident mel batch handed from GlowTTS to HiFi-GAN without a host
+    round trip (the reference crosses host<->runtime twice per sentence,
+    `larynx/__init__.py:231-256`)."""
+
+    def __init__(self, engine: "Engine", handle: int):
+        self._engine = engine
+        self._h = C.c_void_p(handle)
+        lib = engine.lib
+        self.batch = ffi.check(lib, lib.mi355tts_mel_batch(self._h))
+        self.channels = ffi.check(lib, lib.mi355tts_mel_channels(self._h))
+        self.max_frames = ffi.check(lib, lib.mi355tts_mel_max_frames(self._h))
+        fr = (C.c_int32 * self.batch)()
+        ffi.check(lib, lib.mi355tts_mel_frames(self._h, fr))
+        self.frames = np.array(fr[:], dtype=np.int32)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise ValueError("mel batch already freed")
+        return self._h
+
+    def numpy(self, which: str = "raw") -> np.ndarray:
+        """[B, M, max_frames] float32; `which` is "raw" (GlowTTS output) or
+        "vocoder" (after the AudioSettings transforms)."""
+        out = np.zeros((self.batch, self.channels, self.max_frames), np.float32)
+        if self.max_frames:
+            lib = self._engine.lib
+            ffi.check(lib, lib.mi355tts_mel_copy(self.handle, 0 if which == "raw" else 1, out.ctypes.data, self.max_frames))
+        return out
+
+    @property
+    def shape(self):
+        return (self.batch, self.channels, self.max_frames)
+
+    def free(self):
+        if self._h is not None:
+            self._engine.lib.mi355tts_mel_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device: int = 0, library_path=None):
+        self.lib = ffi.load_library(library_path)
+        self.device = device
+        h = C.c_void_p()
+        ffi.check(self.lib, self.lib.mi355tts_create(device, C.byref(h)))
+        self._ctx = h
+        self._lock = threading.Lock()
+        self._hops: typing.Dict[int, int] = {}
+
+    def close(self):
+        if self._ctx is not None:
+            self.lib.mi355tts_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------
+    def glow_blob(self, hp: GlowHParams, state_dict) -> np.ndarray:
+        return build_blob(ffi.manifest(self.lib, ffi.glow_hparams_c(hp)), state_dict)
+
+    def hifigan_blob(self, hp: HifiGanHParams, state_dict) -> np.ndarray:
+        return build_blob(ffi.manifest(self.lib, ffi.hifigan_hparams_c(hp)), state_dict)
+
+    def load_glow(self, hp: GlowHParams, state_dict=None, blob=None, device_ptr: int = 0) -> int:
+        """Load from a reference state-dict, a prebuilt host blob, or a device
+        pointer holding the blob (the receive side of the RCCL weight broadcast)."""
+        hp_c = ffi.glow_hparams_c(hp)
+        return self._load(self.lib.mi355tts_load_glow, hp_c, state_dict, blob, device_ptr)
+
+    def load_hifigan(self, hp: HifiGanHParams, state_dict=None, blob=None, device_ptr: int = 0) -> int:
+        hp_c = ffi.hifigan_hparams_c(hp)
+        return self._load(self.lib.mi355tts_load_hifigan, hp_c, state_dict, blob, device_ptr)
+
+    def _load(self, fn, hp_c, state_dict, blob, device_ptr) -> int:
+        man = ffi.manifest(self.lib, hp_c)
+        total = sum(n for _, n in man)
+        model = C.c_int()
+        if device_ptr:
+            ffi.check(self.lib, fn(self._ctx, C.byref(hp_c), C.c_void_p(device_ptr), total, 1, C.byref(model)))
+        else:
+            if blob is None:
+                blob = build_blob(man, state_dict)
+            blob = np.ascontiguousarray(blob, np.float32)
+            if blob.size != total:
+                raise ValueError(f"blob has {blob.size} floats, model needs {total}")
+            ffi.check(self.lib, fn(self._ctx, C.byref(hp_c), blob.ctypes.data, total, 0, C.byref(model)))
+        return int(model.value)
+
+    def unload(self, model: int):
+        ffi.check(self.lib, self.lib.mi355tts_unload(self._ctx, model))
+
+    # ---- inference -----------------------------------------------------------
+    def glow_infer(
+        self,
+        model: int,
+        ids: typing.Union[np.ndarray, typing.Sequence[np.ndarray]],
+        noise_scale: float = 0.667,
+        length_scale: float = 1.0,
+        noise: typing.Optional[np.ndarray] = None,
+        seed: int = 0,
+        audio_settings=None,
+    ) -> MelBatch:
+        """`ids`: one int64 vector [P] or a list of them (variable length batch).
+        `noise`: optional [B, M, >=F] (or [M, >=F] for B=1) standing in for the
+        reference's `torch.randn_like` draw."""
+        rows = [np.asarray(ids, np.int64)] if isinstance(ids, np.ndarray) and ids.ndim == 1 else [np.asarray(r, np.int64) for r in ids]
+        if isinstance(ids, np.ndarray) and ids.ndim == 2:
+            rows = [np.asarray(r, np.int64) for r in ids]
+        B = len(rows)
+        lens = np.array([len(r) for r in rows], np.int32)
+        ld = int(lens.max()) if B else 0
+        packed = np.zeros((B, max(ld, 1)), np.int64)
+        for b, r in enumerate(rows):
+            packed[b, : len(r)] = r
+        nz_ptr, nz_ld = None, 0
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float32)
+            if noise.ndim == 2:
+                noise = noise[None]
+            if noise.shape[0] != B:
+                raise ValueError("noise batch mismatch")
+            nz_ptr, nz_ld = noise.ctypes.data, noise.shape[2]
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        out = C.c_void_p()
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_glow_infer(
+                self._ctx, model, packed.ctypes.data, lens.ctypes.data_as(C.POINTER(C.c_int32)), B, packed.shape[1],
+                float(noise_scale), float(length_scale), nz_ptr, nz_ld, int(seed) & (2 ** 64 - 1),
+                C.byref(a) if a is not None else None, 0, C.byref(out),
+            ),
+        )
+        return MelBatch(self, out.value)
+
+    def mel_from_numpy(self, mel: np.ndarray, frames=None, audio_settings=None) -> MelBatch:
+        mel = np.ascontiguousarray(mel, np.float32)
+        if mel.ndim == 2:
+            mel = mel[None]
+        B, M, ld = mel.shape
+        fr = np.full(B, ld, np.int32) if frames is None else np.asarray(frames, np.int32)
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        out = C.c_void_p()
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_mel_from_buffer(
+                self._ctx, mel.ctypes.data, fr.ctypes.data_as(C.POINTER(C.c_int32)), B, M, ld,
+                C.byref(a) if a is not None else None, 0, C.byref(out),
+            ),
+        )
+        return MelBatch(self, out.value)
+
+    def hop(self, vocoder: int) -> int:
+        if vocoder not in self._hops:
+            self._hops[vocoder] = ffi.check(self.lib, self.lib.mi355tts_hifigan_hop(self._ctx, vocoder))
+        return self._hops[vocoder]
+
+    def hifigan_infer(self, vocoder: int, mel: MelBatch, want_float: bool = True, want_int16: bool = True):
+        """Returns (wav_f32 [B, N] or None, wav_i16 [B, N] or None), N = max_frames*hop;
+        row b holds frames[b]*hop samples followed by zeros."""
+        n = mel.max_frames * self.hop(vocoder)
+        f32 = np.zeros((mel.batch, n), np.float32) if want_float else None
+        i16 = np.zeros((mel.batch, n), np.int16) if want_int16 else None
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, ffi.ptr(f32), ffi.ptr(i16), n, 0),
+        )
+        return f32, i16
+
+    # ---- single operators ------------------------------------------------------
+    def conv1d(self, x, w, bias=None, dilation=1, in_slope=1.0, out_act=0, lens=None) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        B, Cin, L = x.shape
+        Cout, _, K = w.shape
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        y = np.zeros((B, Cout, L), np.float32)
+        ln = None if lens is None else np.ascontiguousarray(lens, np.int32)
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_op_conv1d(
+                self._ctx, x.ctypes.data, B, Cin, L, None if ln is None else ln.ctypes.data_as(C.POINTER(C.c_int32)),
+                w.ctypes.data, ffi.ptr(b), Cout, K, int(dilation), float(in_slope), int(out_act), y.ctypes.data,
+            ),
+        )
+        return y
+
+    def conv_transpose1d(self, x, w, bias, stride, in_slope=1.0) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        B, Cin, L = x.shape
+        _, Cout, K = w.shape
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        y = np.zeros((B, Cout, L * stride), np.float32)
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_op_conv_transpose1d(
+                self._ctx, x.ctypes.data, B, Cin, L, w.ctypes.data, ffi.ptr(b), Cout, K, int(stride), float(in_slope), y.ctypes.data
+            ),
+        )
+        return y
+
+    # ---- measurement -------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        ffi.check(self.lib, self.lib.mi355tts_set_profiling(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        ffi.check(self.lib, self.lib.mi355tts_profile_reset(self._ctx))
+
+    def profile(self) -> dict:
+        buf = C.create_string_buffer(4096)
+        ffi.check(self.lib, self.lib.mi355tts_profile_json(self._ctx, buf, 4096))
+        return json.loads(buf.value.decode("ascii"))
