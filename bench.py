@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Benchmark of the Larynx hot path on MI355X (contract: see the task brief).
+
+One "step" = one utterance through the whole path — phoneme ids -> GlowTTS ->
+mel transform -> HiFi-GAN 'high' -> float + int16 waveform — at batch 1
+(BASELINE.json configs[1]; standard utterance S of SURVEY.md §8: P = 120 ids,
+ljspeech hyper-parameters, about 624 frames = 7.2 s of audio).  Inputs (ids) and
+outputs (waveforms) are device resident; the only host traffic inside a step is
+the frame-count read-back the data-dependent length needs.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Rank 0
+builds the folded weight blobs and broadcasts them over xGMI once; utterances
+are independent, so the timed region has no collective ("weak" scaling: every
+rank synthesises its own K utterances).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, f32 MFMA = f32 vector peak
+SAMPLE_RATE = 22050
+
+
+def algorithmic_flop(P: int, F: int, quality: str = "high") -> float:
+    """FLOP(P,F,q) = 2*[7142656 P + 6(384 P^2 + 3456 P) + 10675968 F + H_q F]."""
+    H = {"high": 307052544, "medium": 19255296, "low": 22482944}[quality]
+    return 2.0 * (7142656.0 * P + 6.0 * (384.0 * P * P + 3456.0 * P) + 10675968.0 * F + H * F)
+
+
+def cpu_baseline(max_seconds: float = 30.0):
+    """The CPU oracle (numpy port of the reference's torch path) timed on this
+    box's host cores on a bounded sample: the 28-id fixture sentence
+    `be_a_voice_not_an_echo` through GlowTTS + HiFi-GAN 'high'."""
+    from larynx_amd import hparams as HP
+    from larynx_amd import synthetic
+    from larynx_amd.audio import ljspeech_audio_settings
+    from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+    ids = np.array([3, 8, 4, 14, 3, 35, 3, 26, 4, 34, 22, 3, 1, 3, 19, 4, 32, 23, 3, 35, 19, 3, 4, 37, 16, 20, 3, 2], np.int64)
+    gsd = synthetic.make_glow_state_dict(HP.LJSPEECH, seed=1234)
+    vsd = synthetic.make_hifigan_state_dict(HP.HIFIGAN_HIGH, seed=1234)
+    noise = np.random.default_rng(1234).standard_normal((80, 16 * len(ids) + 64)).astype(np.float32)
+    s = ljspeech_audio_settings()
+    times = []
+    t_all = time.perf_counter()
+    F = 0
+    while len(times) < 3 and (time.perf_counter() - t_all) < max_seconds:
+        t0 = time.perf_counter()
+        mel = glow_tts_np.glow_tts_infer(gsd, HP.LJSPEECH, ids, noise, 0.667, 1.0)
+        wav = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_HIGH, audio_np.mel_to_vocoder_input(mel, s))
+        audio_np.audio_float_to_int16(wav)
+        times.append(time.perf_counter() - t0)
+        F = mel.shape[1]
+    best = min(times)
+    audio_s = F * 256 / SAMPLE_RATE
+    rtf = best / audio_s
+    return {
+        "value": 1.0 / (rtf * 624 * 256 / SAMPLE_RATE),
+        "unit": "utterances/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "rtf": rtf,
+        "x_realtime": 1.0 / rtf,
+        "sample": f"numpy oracle (OpenBLAS, {os.cpu_count()} threads), fixture sentence be_a_voice_not_an_echo: 28 ids -> {F} frames = "
+                  f"{audio_s:.2f} s audio, min of {len(times)} runs = {best:.2f} s; value = standard 624-frame utterances/s at that RTF",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ids", type=int, default=120, help="phoneme ids per utterance")
+    ap.add_argument("--quality", default="high")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from larynx_amd import ffi
+    from larynx_amd import hparams as HP
+    from larynx_amd import synthetic
+    from larynx_amd.audio import ljspeech_audio_settings
+    from larynx_amd.engine import Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    eng = Engine(device=local)
+    ghp, vhp = HP.LJSPEECH, HP.VOCODER_QUALITY[args.quality]
+    # ---- weights: rank 0 folds, everyone receives over RCCL/xGMI
+    man_g = ffi.manifest(eng.lib, ffi.glow_hparams_c(ghp))
+    man_v = ffi.manifest(eng.lib, ffi.hifigan_hparams_c(vhp))
+    n_g, n_v = sum(n for _, n in man_g), sum(n for _, n in man_v)
+    blob = torch.empty(n_g + n_v, dtype=torch.float32, device=dev)
+    if rank == 0:
+        from larynx_amd.weights import build_blob
+
+        bg = build_blob(man_g, synthetic.make_glow_state_dict(ghp, seed=1234))
+        bv = build_blob(man_v, synthetic.make_hifigan_state_dict(vhp, seed=1234))
+        blob.copy_(torch.from_numpy(np.concatenate([bg, bv])))
+    if world > 1:
+        dist.broadcast(blob, src=0)
+    torch.cuda.synchronize()
+    g = eng.load_glow(ghp, device_ptr=blob.data_ptr())
+    v = eng.load_hifigan(vhp, device_ptr=blob.data_ptr() + 4 * n_g)
+    del blob
+
+    # ---- synthetic utterances (one per step per rank), resident in HBM
+    rng = np.random.default_rng(1234 + rank)
+    n_utts = args.steps + args.warmup
+    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(n_utts)])
+    ids_dev = torch.from_numpy(ids_host).to(dev)
+    lens = np.array([args.ids], np.int32)
+    hop = vhp.hop
+    max_samples = args.ids * 12 * hop
+    wav_f32 = torch.empty(max_samples, dtype=torch.float32, device=dev)
+    wav_i16 = torch.empty(max_samples, dtype=torch.int16, device=dev)
+    s = ljspeech_audio_settings()
+
+    def step(i):
+        mel = eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, 1.0, None, 0, seed=1234 + i,
+                                 audio_settings=s, flags=ffi.IN_DEVICE)
+        eng.hifigan_infer_raw(v, mel, wav_f32.data_ptr(), wav_i16.data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
+        f = int(mel.frames[0])
+        mel.free()
+        return f
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    eng.set_profiling(True)
+    eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(args.warmup, n_utts):
+        frames += step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.set_profiling(False)
+
+    # a second, event-free pass of the same steps: the headline time must not
+    # carry the profiling events' overhead
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(args.warmup, n_utts):
+        step(i)
+    barrier()
+    dt_clean = time.perf_counter() - t1
+
+    stats = torch.tensor([dt_clean, dt, float(frames)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt_clean, dt = float(mx[0]), float(mx[1])
+        total_frames = float(sm[2])
+    else:
+        total_frames = float(frames)
+
+    if rank == 0:
+        K = args.steps
+        audio_s = total_frames * hop / SAMPLE_RATE
+        utt_s = world * K / dt_clean
+        fpu = total_frames / (world * K)
+        dom = prof["conv_mfma.hifigan_resblock"]
+        dom_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        all_conv_ms = sum(v_["ms"] for k_, v_ in prof.items() if k_.startswith("conv_mfma"))
+        out = {
+            "metric": "utterances_per_sec",
+            "value": utt_s,
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_clean / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"en-us ljspeech GlowTTS + hifi_gan '{args.quality}', batch=1, {args.ids} phoneme ids per utterance "
+                            f"(~{fpu:.0f} frames = {fpu * hop / SAMPLE_RATE:.2f} s audio), seeded random weights, device RNG noise",
+                "ids_per_utterance": args.ids,
+                "frames_per_utterance": fpu,
+                "parallelism": f"utterance-dp{world}",
+            },
+            "rtf": dt_clean * world / audio_s,
+            "x_realtime_per_gpu": audio_s / (dt_clean * world),
+            "end_to_end_tflops_per_gpu": algorithmic_flop(args.ids, fpu, args.quality) * K / dt_clean / 1e12,
+            "roofline": {
+                "kernel": "conv_mfma_kernel (HiFi-GAN ResBlock convs)",
+                "bound": "mfma",
+                "achieved": dom_tf,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": dom_tf / FP32_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": dom["launches"],
+                "avg_launch_us": 1e3 * dom["ms"] / max(1, dom["launches"]),
+                "share_of_step_time": dom["ms"] / (1e3 * dt),
+                "all_conv_mfma_ms_per_step": all_conv_ms / K,
+                "timing": "HIP events on the launch stream around every launch, profiled pass of the same K steps",
+            },
+            "profile_ms_per_step": {k_: v_["ms"] / K for k_, v_ in prof.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

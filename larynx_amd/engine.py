@@ -160,6 +160,25 @@ class Engine:
         )
         return MelBatch(self, out.value)
 
+    def glow_infer_raw(self, model, ids_ptr, lens, ids_ld, noise_scale, length_scale, noise_ptr=None, noise_ld=0,
+                       seed=0, audio_settings=None, flags=0) -> MelBatch:
+        """Pointer-level entry (ids/noise may be device memory with flags=ffi.IN_DEVICE)."""
+        lens = np.ascontiguousarray(lens, np.int32)
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        out = C.c_void_p()
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_glow_infer(
+                self._ctx, model, ids_ptr, lens.ctypes.data_as(C.POINTER(C.c_int32)), len(lens), ids_ld,
+                float(noise_scale), float(length_scale), noise_ptr, noise_ld, int(seed) & (2 ** 64 - 1),
+                C.byref(a) if a is not None else None, flags, C.byref(out),
+            ),
+        )
+        return MelBatch(self, out.value)
+
+    def hifigan_infer_raw(self, vocoder, mel: MelBatch, f32_ptr, i16_ptr, wav_ld, flags=0):
+        ffi.check(self.lib, self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, f32_ptr, i16_ptr, wav_ld, flags))
+
     def mel_from_numpy(self, mel: np.ndarray, frames=None, audio_settings=None) -> MelBatch:
         mel = np.ascontiguousarray(mel, np.float32)
         if mel.ndim == 2:

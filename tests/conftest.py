@@ -33,8 +33,6 @@ def emu_engine(emu_library):
 
 @pytest.fixture(scope="session")
 def gpu_engine():
-    import torch  # noqa: F401  (device plumbing only)
-
     from larynx_amd.engine import Engine
 
     eng = Engine(device=0)

@@ -1,0 +1,102 @@
+"""Whole hot path (GlowTTS -> mel transform -> HiFi-GAN -> int16) through the C
+ABI on the CPU emulator build, at shrunk hyper-parameters, against the numpy
+oracle.  Exercises the host schedule, weight folding/packing, every kernel's
+index logic and the batch/padding path without a GPU."""
+import numpy as np
+import pytest
+
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+
+@pytest.fixture(scope="module")
+def tiny_models(emu_engine):
+    gsd = synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7)
+    vsd = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7)
+    vsd2 = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN_RB2, seed=8)
+    return dict(
+        gsd=gsd, vsd=vsd, vsd2=vsd2,
+        g=emu_engine.load_glow(HP.TINY_GLOW, gsd),
+        v=emu_engine.load_hifigan(HP.TINY_HIFIGAN, vsd),
+        v2=emu_engine.load_hifigan(HP.TINY_HIFIGAN_RB2, vsd2),
+    )
+
+
+def _ids(rng, n):
+    return synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols)
+
+
+def test_glow_single_utterance(emu_engine, tiny_models):
+    rng = np.random.default_rng(3)
+    ids = _ids(rng, 23)
+    noise = rng.standard_normal((HP.TINY_GLOW.mel_channels, 400)).astype(np.float32)
+    taps = {}
+    ref = glow_tts_np.glow_tts_infer(tiny_models["gsd"], HP.TINY_GLOW, ids, noise, 0.667, 1.0, taps)
+    mel = emu_engine.glow_infer(tiny_models["g"], ids, 0.667, 1.0, noise=noise, audio_settings=ljspeech_audio_settings())
+    assert mel.frames[0] == ref.shape[1]
+    got = mel.numpy("raw")[0]
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-4)
+    voc = audio_np.mel_to_vocoder_input(ref, ljspeech_audio_settings())
+    np.testing.assert_allclose(mel.numpy("vocoder")[0], voc, atol=2e-3, rtol=1e-4)
+
+
+def test_glow_variable_length_batch_equals_rowwise(emu_engine, tiny_models):
+    """the reference never batches; each row of a padded batch must
+    equal its own B=1 result and the padded tail must be exactly zero."""
+    rng = np.random.default_rng(4)
+    rows = [_ids(rng, n) for n in (9, 30, 17)]
+    M = HP.TINY_GLOW.mel_channels
+    noise = rng.standard_normal((3, M, 400)).astype(np.float32)
+    mel = emu_engine.glow_infer(tiny_models["g"], rows, 0.5, 1.1, noise=noise)
+    got = mel.numpy("raw")
+    for b, ids in enumerate(rows):
+        ref = glow_tts_np.glow_tts_infer(tiny_models["gsd"], HP.TINY_GLOW, ids, noise[b], 0.5, 1.1)
+        F = ref.shape[1]
+        assert mel.frames[b] == F
+        np.testing.assert_allclose(got[b, :, :F], ref, atol=2e-5, rtol=1e-4)
+        assert np.all(got[b, :, F:] == 0)
+
+
+@pytest.mark.parametrize("which", ["v", "v2"])
+def test_hifigan_batch(emu_engine, tiny_models, which):
+    hp = HP.TINY_HIFIGAN if which == "v" else HP.TINY_HIFIGAN_RB2
+    sd = tiny_models["vsd" if which == "v" else "vsd2"]
+    rng = np.random.default_rng(5)
+    frames = np.array([37, 12], np.int32)
+    melin = (rng.standard_normal((2, hp.num_mels, 37)) * 2).astype(np.float32)
+    mb = emu_engine.mel_from_numpy(melin, frames)
+    f32, i16 = emu_engine.hifigan_infer(tiny_models[which], mb)
+    hop = hp.hop
+    for b in range(2):
+        ref = hifi_gan_np.hifigan_infer(sd, hp, melin[b, :, : frames[b]])
+        n = frames[b] * hop
+        assert ref.shape[0] == n
+        err = f32[b, :n] - ref
+        assert np.sqrt(np.mean(err ** 2)) < 1e-5, np.abs(err).max()
+        assert np.all(f32[b, n:] == 0) and np.all(i16[b, n:] == 0)
+        ref16 = audio_np.audio_float_to_int16(ref)
+        assert np.abs(i16[b, :n].astype(np.int32) - ref16.astype(np.int32)).max() <= 1
+
+
+def test_end_to_end_tiny(emu_engine, tiny_models):
+    rng = np.random.default_rng(6)
+    ids = _ids(rng, 12)
+    s = ljspeech_audio_settings()
+    mel = emu_engine.glow_infer(tiny_models["g"], ids, 0.0, 1.0, audio_settings=s)
+    f32, i16 = emu_engine.hifigan_infer(tiny_models["v"], mel)
+    ref_mel = glow_tts_np.glow_tts_infer(tiny_models["gsd"], HP.TINY_GLOW, ids, None, 0.0, 1.0)
+    ref_wav = hifi_gan_np.hifigan_infer(tiny_models["vsd"], HP.TINY_HIFIGAN, audio_np.mel_to_vocoder_input(ref_mel, s))
+    assert f32.shape[1] == ref_wav.shape[0]
+    assert np.sqrt(np.mean((f32[0] - ref_wav) ** 2)) < 1e-4
+
+
+def test_errors_are_reported_not_crashed(emu_engine, tiny_models):
+    from larynx_amd.ffi import Mi355ttsError
+
+    with pytest.raises(Mi355ttsError):
+        emu_engine.glow_infer(999, np.array([3, 4, 2]))
+    with pytest.raises(Mi355ttsError):  # noise too short for the utterance
+        emu_engine.glow_infer(tiny_models["g"], _ids(np.random.default_rng(1), 20), 0.667, 1.0,
+                              noise=np.zeros((HP.TINY_GLOW.mel_channels, 4), np.float32))

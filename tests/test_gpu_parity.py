@@ -1,0 +1,169 @@
+"""Parity of the HIP path (through the C ABI, on a real MI355X) against the
+golden vectors produced by the reference's torch modules and against the CPU
+oracle.  Tolerances are north_star's: mel +-1e-3 max-abs, waveform 1e-4 RMS,
+identical frame counts, int16 within 1 LSB."""
+import numpy as np
+import pytest
+
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from oracle import audio_np, glow_tts_np, hifi_gan_np, nn_np
+from tests.golden_util import CASES, load_case
+from tests.test_emu_conv import CASES as CONV_CASES
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-3
+WAV_RMS_TOL = 1e-4
+
+_models = {}
+
+
+def models(eng, ghp, vhp):
+    if ("g", ghp) not in _models:
+        sd = synthetic.make_glow_state_dict(ghp, seed=1234)
+        _models[("g", ghp)] = (sd, eng.load_glow(ghp, sd))
+    if ("v", vhp) not in _models:
+        sd = synthetic.make_hifigan_state_dict(vhp, seed=1234)
+        _models[("v", vhp)] = (sd, eng.load_hifigan(vhp, sd))
+    return _models[("g", ghp)], _models[("v", vhp)]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,dil,L,B,slope,act", CONV_CASES + [(256, 256, 11, 5, 4992, 1, 0.1, 0), (32, 32, 3, 1, 159744, 1, 0.1, 0)])
+def test_conv1d_kernel(gpu_engine, Cin, Cout, K, dil, L, B, slope, act):
+    rng = np.random.default_rng(Cin * 1000 + Cout + K)
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    lens = np.array([L] + [L - 37] * (B - 1), np.int32)
+    y = gpu_engine.conv1d(x, w, b, dilation=dil, in_slope=slope, out_act=act, lens=lens)
+    for i in range(B):
+        n = lens[i]
+        ref = nn_np.conv1d(nn_np.leaky_relu(x[i, :, :n], slope), w, b, dilation=dil, padding=(K * dil - dil) // 2)
+        if act == 1:
+            ref = np.maximum(ref, 0)
+        elif act == 2:
+            ref = np.tanh(ref)
+        np.testing.assert_allclose(y[i, :, :n], ref, rtol=1e-4, atol=5e-5)
+        assert np.all(y[i, :, n:] == 0)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,u,L", [(16, 8, 16, 8, 50), (512, 256, 16, 8, 624), (64, 32, 4, 2, 5000)])
+def test_conv_transpose1d_kernel(gpu_engine, Cin, Cout, K, u, L):
+    rng = np.random.default_rng(K * 100 + u)
+    x = rng.standard_normal((1, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * 2)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = gpu_engine.conv_transpose1d(x, w, b, stride=u, in_slope=0.1)
+    ref = nn_np.conv_transpose1d(nn_np.leaky_relu(x[0], 0.1), w, b, stride=u, padding=(K - u) // 2)
+    np.testing.assert_allclose(y[0], ref, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_reference_parity(gpu_engine, name):
+    """HIP path vs outputs of the reference's own torch implementation."""
+    c = load_case(name)
+    (gsd, g), (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    s = ljspeech_audio_settings()
+    mel = gpu_engine.glow_infer(g, c["ids"], float(c["noise_scale"]), float(c["length_scale"]), noise=c["noise"], audio_settings=s)
+    assert int(mel.frames[0]) == c["mel"].shape[1]
+    raw = mel.numpy("raw")[0]
+    assert np.abs(raw - c["mel"]).max() <= MEL_TOL
+    # tighter than north_star: the path is exact f32 MFMA, expect f32 round-off only
+    assert np.abs(raw - c["mel"]).max() <= 5e-5
+    np.testing.assert_allclose(mel.numpy("vocoder")[0], c["mel_voc"], atol=5e-3, rtol=1e-3)
+    wav, i16 = gpu_engine.hifigan_infer(v, mel)
+    st = int(c["wav_stride"])
+    rms = np.sqrt(np.mean((wav[0][::st] - c["wav"]) ** 2))
+    assert rms <= WAV_RMS_TOL, rms
+    assert np.abs(i16[0][::st].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 2  # 1 LSB + peak round-off
+
+
+def test_vocoder_alone_on_reference_mel(gpu_engine):
+    """`mels_to_audio` drop-in: host mel (already transformed) in, int16 out."""
+    c = load_case("ljspeech_high_echo")
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    wav, i16 = gpu_engine.hifigan_infer(v, mb)
+    assert np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)) <= 2e-5
+    assert np.abs(i16[0].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 1
+
+
+def test_batch_rows_equal_single_rows(gpu_engine):
+    """BASELINE config 4 shape: thorsten + 'medium', B=8 variable length; every
+    row must equal its own B=1 result, padded tails exactly 0."""
+    ghp, vhp = HP.THORSTEN, HP.HIFIGAN_MEDIUM
+    (gsd, g), (vsd, v) = models(gpu_engine, ghp, vhp)
+    rng = np.random.default_rng(11)
+    lens = [19, 26, 31, 33, 64, 47, 90, 120]
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, ghp.num_symbols) for n in lens]
+    noise = rng.standard_normal((8, 80, 2200)).astype(np.float32)
+    s = ljspeech_audio_settings()
+    mel = gpu_engine.glow_infer(g, rows, 0.667, 1.0, noise=noise, audio_settings=s)
+    wav, i16 = gpu_engine.hifigan_infer(v, mel)
+    raw = mel.numpy("raw")
+    hop = vhp.hop
+    for b in (0, 3, 7):
+        one = gpu_engine.glow_infer(g, rows[b], 0.667, 1.0, noise=noise[b], audio_settings=s)
+        F = int(one.frames[0])
+        assert int(mel.frames[b]) == F
+        np.testing.assert_allclose(raw[b, :, :F], one.numpy("raw")[0], atol=1e-5)
+        assert np.all(raw[b, :, F:] == 0)
+        w1, _ = gpu_engine.hifigan_infer(v, one)
+        assert np.sqrt(np.mean((wav[b, : F * hop] - w1[0]) ** 2)) <= 1e-5
+        assert np.all(wav[b, F * hop :] == 0) and np.all(i16[b, F * hop :] == 0)
+    # and against the oracle for the shortest row
+    ref = glow_tts_np.glow_tts_infer(gsd, ghp, rows[0], noise[0], 0.667, 1.0)
+    assert np.abs(raw[0, :, : ref.shape[1]] - ref).max() <= 5e-5
+
+
+def test_standard_utterance_properties(gpu_engine):
+    """BASELINE config 2 at full size (P=120): size-independent checks — frame
+    count equals the duration sum, bounded tanh output, int16 peak-normalised,
+    determinism, and noise_scale=0 equals noise=None."""
+    ghp, vhp = HP.LJSPEECH, HP.HIFIGAN_HIGH
+    (gsd, g), (vsd, v) = models(gpu_engine, ghp, vhp)
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(1234), 120, ghp.num_symbols)
+    s = ljspeech_audio_settings()
+    taps = {}
+    glow_tts_np.text_encoder(gsd, ids, ghp, taps)
+    w_ceil, F, _ = glow_tts_np.durations_to_frames(taps["logw"], 1.0, 2)
+    noise = np.random.default_rng(1234).standard_normal((80, 1400)).astype(np.float32)
+    mel = gpu_engine.glow_infer(g, ids, 0.667, 1.0, noise=noise, audio_settings=s)
+    assert int(mel.frames[0]) == F
+    wav, i16 = gpu_engine.hifigan_infer(v, mel)
+    assert wav.shape[1] == F * 256 and np.all(np.abs(wav) < 1.0) and np.isfinite(wav).all()
+    assert np.abs(i16).max() == 32767 or np.abs(wav).max() < 0.01
+    mel2 = gpu_engine.glow_infer(g, ids, 0.667, 1.0, noise=noise, audio_settings=s)
+    wav2, _ = gpu_engine.hifigan_infer(v, mel2)
+    assert np.array_equal(wav, wav2)
+    a = gpu_engine.glow_infer(g, ids, 0.0, 1.0, noise=noise).numpy()
+    b = gpu_engine.glow_infer(g, ids, 0.0, 1.0).numpy()
+    assert np.array_equal(a, b)
+    # device RNG: different seeds differ, same seed repeats
+    r1 = gpu_engine.glow_infer(g, ids, 0.667, 1.0, seed=1).numpy()
+    r2 = gpu_engine.glow_infer(g, ids, 0.667, 1.0, seed=1).numpy()
+    r3 = gpu_engine.glow_infer(g, ids, 0.667, 1.0, seed=2).numpy()
+    assert np.array_equal(r1, r2) and not np.array_equal(r1, r3)
+
+
+def test_threads_share_one_engine(gpu_engine):
+    """The reference calls its models from a ThreadPoolExecutor (larynx/__init__.py:146)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    ghp, vhp = HP.LJSPEECH, HP.HIFIGAN_MEDIUM
+    (gsd, g), (vsd, v) = models(gpu_engine, ghp, vhp)
+    rng = np.random.default_rng(5)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, ghp.num_symbols) for n in (20, 35, 50, 28, 41, 33)]
+    s = ljspeech_audio_settings()
+
+    def run(ids):
+        m = gpu_engine.glow_infer(g, ids, 0.0, 1.0, audio_settings=s)
+        return gpu_engine.hifigan_infer(v, m)[0][0]
+
+    serial = [run(r) for r in rows]
+    with ThreadPoolExecutor(4) as ex:
+        par = list(ex.map(run, rows))
+    for a, b in zip(serial, par):
+        assert np.array_equal(a, b)

@@ -1,0 +1,60 @@
+"""The CPU oracle against the committed golden vectors, which are outputs of the
+REFERENCE's own torch modules (`oracle/make_golden.py`, run where /root/reference
+exists).  Runs everywhere, no GPU, no torch."""
+import json
+
+import numpy as np
+import pytest
+
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from oracle import audio_np, glow_tts_np, hifi_gan_np
+from tests.golden_util import CASES, GOLDEN, load_case
+
+_cache = {}
+
+
+def _glow_sd(hp):
+    if hp not in _cache:
+        _cache[hp] = synthetic.make_glow_state_dict(hp, seed=1234)
+    return _cache[hp]
+
+
+def test_golden_report_shows_oracle_pinned():
+    rep = json.loads((GOLDEN / "oracle_vs_reference.json").read_text())
+    assert set(rep) == set(CASES)
+    for name, e in rep.items():
+        assert e["mel"] < 2e-5 and e["wav_rms"] < 5e-6 and e["i16"] <= 1, (name, e)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_glow_reproduces_reference(name):
+    c = load_case(name)
+    taps = {}
+    mel = glow_tts_np.glow_tts_infer(_glow_sd(c["glow_hp"]), c["glow_hp"], c["ids"], c["noise"], float(c["noise_scale"]), float(c["length_scale"]), taps)
+    assert mel.shape == c["mel"].shape  # frame count is an integer parity item
+    np.testing.assert_allclose(taps["logw"], c["logw"], atol=2e-5)
+    np.testing.assert_allclose(mel, c["mel"], atol=2e-5)
+    voc = audio_np.mel_to_vocoder_input(mel, ljspeech_audio_settings())
+    np.testing.assert_allclose(voc, c["mel_voc"], atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if "high" not in n or "short" in n])
+def test_oracle_hifigan_reproduces_reference(name):
+    c = load_case(name)
+    vsd = synthetic.make_hifigan_state_dict(c["voc_hp"], seed=1234)
+    wav = hifi_gan_np.hifigan_infer(vsd, c["voc_hp"], c["mel_voc"])
+    st = int(c["wav_stride"])
+    assert np.sqrt(np.mean((wav[::st] - c["wav"]) ** 2)) < 5e-6
+    i16 = audio_np.audio_float_to_int16(wav)[::st]
+    assert np.abs(i16.astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 1
+
+
+def test_duration_expansion_edge_cases():
+    # frame -> id map of `generate_path` (glow_tts/utils.py:99-115), odd total truncated
+    logw = np.log(np.array([1.0, 2.5, 0.2, 3.0], np.float32))
+    w_ceil, F, idx = glow_tts_np.durations_to_frames(logw, 1.0, 2)
+    assert list(w_ceil) == [1, 3, 1, 3] and F == 8
+    assert list(idx) == [0, 1, 1, 1, 2, 3, 3, 3]
+    _, F, idx = glow_tts_np.durations_to_frames(np.log(np.array([1.0, 2.0], np.float32)), 1.0, 2)
+    assert F == 2 and list(idx) == [0, 1]  # 3 frames -> truncated to 2
