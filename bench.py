@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ids", type=int, default=120, help="phoneme ids per utterance")
     ap.add_argument("--quality", default="high")
+    ap.add_argument("--length-scale", type=float, default=0.65,
+                    help="GlowTTS length_scale; 0.65 puts the synthetic 120-id utterances at SURVEY's standard ~624 frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,7 +142,7 @@ def main():
     s = ljspeech_audio_settings()
 
     def step(i):
-        mel = eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, 1.0, None, 0, seed=1234 + i,
+        mel = eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, args.length_scale, None, 0, seed=1234 + i,
                                  audio_settings=s, flags=ffi.IN_DEVICE)
         eng.hifigan_infer_raw(v, mel, wav_f32.data_ptr(), wav_i16.data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
         f = int(mel.frames[0])
@@ -211,6 +213,7 @@ def main():
                 "workload": f"en-us ljspeech GlowTTS + hifi_gan '{args.quality}', batch=1, {args.ids} phoneme ids per utterance "
                             f"(~{fpu:.0f} frames = {fpu * hop / SAMPLE_RATE:.2f} s audio), seeded random weights, device RNG noise",
                 "ids_per_utterance": args.ids,
+                "length_scale": args.length_scale,
                 "frames_per_utterance": fpu,
                 "parallelism": f"utterance-dp{world}",
             },

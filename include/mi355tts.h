@@ -144,6 +144,13 @@ int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L,
 int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const float* w,
                                  const float* bias, int Cout, int K, int stride, float in_slope, float* y);
 
+/* Kernel micro-benchmark: `iters` back-to-back launches of the conv kernel on
+ * device-resident random data of the given geometry (tile_shape -1 = the
+ * launcher's own choice, 0/1/2 = pinned), timed with HIP events on the launch
+ * stream; *ms_per_launch receives the average. */
+int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, int dilation, int L, int tile_shape,
+                          int iters, float* ms_per_launch);
+
 /* ---- measurement -------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * call's own stream and accumulated per kernel class.  `mi355tts_profile_json`

@@ -8,8 +8,9 @@
 // N = time (B = activations, staged through LDS with the input activation applied
 // once per element, halo included), K-dim = (ci, tap).
 //
-// One workgroup = 4 waves = (MB*32) output rows x (4*NB*32) time columns; each
-// wave owns MB x NB MFMA blocks of 32x32 (16 accumulator VGPRs each).
+// One workgroup = WN x KS waves = (MB*32) output rows x (WN*NB*32) time columns;
+// each wave owns MB x NB MFMA blocks of 32x32 (16 accumulator VGPRs each) over its
+// k-group's share of the input channels.
 //
 // This one kernel covers every dense contraction on the Larynx hot path
 // (reference ops): HiFi-GAN conv_pre / ResBlock convs / conv_post
@@ -73,22 +74,37 @@ struct ConvArgs {
   int half;
 };
 
-template <int K, int CI_C, int MB, int NB, int HALO, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int T_T = 4 * NB * 32;  // time columns per workgroup
-  constexpr int XW = T_T + HALO;    // LDS row stride (floats)
-  constexpr int NR = CI_C / 4;      // staging rows per thread
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+__global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs a) {
+  // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
+  // (NB blocks of 32 columns each); the KS k-groups split the staged input
+  // channels between them (octet o goes to group o % KS) and are summed through
+  // LDS before the epilogue: two (or four) waves per SIMD from ONE staged tile,
+  // which is what hides the LDS/L2 latencies at batch 1 where there are fewer
+  // tiles than SIMDs.
+  constexpr int NWAVES = WN * KS;
+  constexpr int NT = 64 * NWAVES;
+  constexpr int T_T = WN * NB * 32;  // time columns per workgroup
+  constexpr int XW = T_T + HALO;     // LDS row stride (floats)
+  constexpr int NR = CI_C / NWAVES;  // staging rows per thread
   constexpr int NC = (XW + 63) / 64;
-  constexpr int S = (CI_C / 8) * K;  // k-steps (8 channels x 1 tap) per staged chunk
-  static_assert(CI_C % 8 == 0, "CI_C must be a multiple of 8");
+  constexpr int OCTS = CI_C / 8;     // octets per staged chunk
+  constexpr int NO = OCTS / KS;      // octets per chunk per k-group
+  constexpr int S = NO * K;          // MFMA k-steps per chunk per k-group
+  constexpr int RED = (KS - 1) * WN * NB * 16 * 64;
+  constexpr int XS = 2 * CI_C * XW;
+  constexpr int LDSF = XS > RED ? XS : RED;
+  static_assert(CI_C % 8 == 0 && CI_C % NWAVES == 0 && OCTS % KS == 0, "bad tile parameters");
 
-  __shared__ float xs[2 * CI_C * XW];
+  __shared__ float xs[LDSF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int tx = tid & 63;
-  const int ty = tid >> 6;
+  const int wn = wave % WN;
+  const int kg = wave / WN;
+  const int tx = lane;
+  const int ty = wave;
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * T_T;
   const int mt0 = blockIdx.y * MB;
@@ -102,20 +118,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int roww = T_T + (K - 1) * a.dil;  // staged columns actually used
   const float slope = a.in_slope;
   const float* xb = a.x + (long long)b * a.x_bs;
-  const int nchunks = (a.noct * 8 + CI_C - 1) / CI_C;
+  const int nchunks = a.noct / OCTS;  // noct is padded to a multiple of OCTS at pack time
 
+  // ---- staging of the activation tile (global -> VGPR -> LDS), branch-free:
+  // every lane loads from a clamped in-range address and zeroes by select, so the
+  // loads issue back to back instead of one exec-masked branch each.
   float pre[NR * NC];
+  const int cin_last = a.Cin - 1;
+  const int lin_last = Lin - 1;
   auto gload = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int ci = chunk * CI_C + ty + 4 * i;
-      const float* xr = xb + (long long)ci * a.x_ld;
+      const int ci = chunk * CI_C + ty + NWAVES * i;
+      const bool row_ok = ci < a.Cin;
+      const float* xr = xb + (long long)(row_ok ? ci : cin_last) * a.x_ld;
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int cc = tx + 64 * j;
         const int ti = t0 - a.pad + cc;
-        float v = 0.f;
-        if (cc < roww && ci < a.Cin && ti >= 0 && ti < Lin) v = xr[ti];
+        const bool ok = row_ok && cc < roww && ti >= 0 && ti < Lin;
+        const int tc = ti < 0 ? 0 : (ti > lin_last ? lin_last : ti);
+        float v = xr[tc];
+        v = ok ? v : 0.f;
         v = v > 0.f ? v : v * slope;
         pre[i * NC + j] = v;
       }
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int cc = tx + 64 * j;
-        if (cc < XW) dst[(ty + 4 * i) * XW + cc] = pre[i * NC + j];
+        if (cc < XW) dst[(ty + NWAVES * i) * XW + cc] = pre[i * NC + j];
       }
     }
   };
@@ -141,57 +165,131 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-  // A-fragment stream of m-tile mt: float4 index ((mt*noct + oct)*K + k)*64 + lane
+  // A-fragment stream of m-tile mt: float4 index ((mt*noct + oct)*K + k)*64 + lane.
+  // This k-group walks steps q = 0..S-1 per chunk: octet kg + (q/K)*KS, tap q%K.
   const float4* wq[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
     wq[mb] = reinterpret_cast<const float4*>(a.w) + (long long)(mt0 + mb) * a.noct * K * 64 + lane;
-  const int total_steps = a.noct * K;
+  const int last_chunk = nchunks - 1;
+  auto a_index = [&](int chunk, int q) -> long long {
+    // q may run past this chunk (prefetch): roll into the next one, clamp at the end
+    if (q >= S) {
+      if (chunk < last_chunk) {
+        chunk += 1;
+        q -= S;
+      } else {
+        q = S - 1;
+      }
+    }
+    const int oi = q / K;
+    const int k = q - oi * K;
+    return (long long)(((chunk * OCTS + kg + oi * KS) * K + k)) * 64;
+  };
 
   gload(0);
   lstore(0);
   __syncthreads();
 
-  float4 a_cur[MB];
+  // 3-deep register ring of A fragments: step q uses ar[q % 3] while the loads
+  // for steps q+1 and q+2 are in flight (L2 latency ~ one MFMA step)
+  float4 ar[3][MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) a_cur[mb] = wq[mb][0];
+  for (int mb = 0; mb < MB; ++mb) {
+    ar[0][mb] = wq[mb][a_index(0, 0)];
+    ar[1][mb] = wq[mb][a_index(0, 1)];
+  }
 
-  const int b_off = (lane >> 5) * XW + wave * (NB * 32) + (lane & 31);
+  const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31);
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
-    if (chunk + 1 < nchunks) gload(chunk + 1);
-    const float* xt = xs + buf * (CI_C * XW) + b_off;
+    const bool more = chunk < last_chunk;
+    if (more) gload(chunk + 1);
+    const float* xt = xs + buf * (CI_C * XW) + b_off + kg * 8 * XW;
+    float bcur[4][NB], bnxt[4][NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = xt[(2 * j) * XW + nb * 32];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      const int gs = chunk * S + s;
-      if (gs < total_steps) {  // uniform; false only in a ragged last chunk
-        const int o = s / K;
-        const int k = s - o * K;
-        float4 a_nxt[MB];
-        const int gn = (gs + 1 < total_steps) ? gs + 1 : gs;
+      // issue the loads for later steps first, then this step's MFMAs
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = wq[mb][(long long)gn * 64];
-        const float* bp = xt + (o * 8) * XW + k * a.dil;
+      for (int mb = 0; mb < MB; ++mb) ar[(s + 2) % 3][mb] = wq[mb][a_index(chunk, s + 2)];
+      if (s + 1 < S) {
+        const int oi = (s + 1) / K;
+        const int k = (s + 1) - oi * K;
+        const float* bp = xt + (oi * KS * 8) * XW + k * a.dil;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float bv[NB];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[(2 * j) * XW + nb * 32];
+          for (int nb = 0; nb < NB; ++nb) bnxt[j][nb] = bp[(2 * j) * XW + nb * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const float av = (j == 0) ? a_cur[mb].x : (j == 1) ? a_cur[mb].y : (j == 2) ? a_cur[mb].z : a_cur[mb].w;
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nb], acc[mb][nb], 0, 0, 0);
-          }
+        for (int mb = 0; mb < MB; ++mb) {
+          const float4 af = ar[s % 3][mb];
+          const float av = (j == 0) ? af.x : (j == 1) ? af.y : (j == 2) ? af.z : af.w;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[j][nb], acc[mb][nb], 0, 0, 0);
         }
+      }
+      if (s + 1 < S) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = bnxt[j][nb];
       }
     }
-    if (chunk + 1 < nchunks) lstore(buf ^ 1);
+    // re-base the ring for the next chunk: its steps 0,1 sit in slots S%3, (S+1)%3
+    {
+      float4 r0[MB], r1[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        r0[mb] = ar[S % 3][mb];
+        r1[mb] = ar[(S + 1) % 3][mb];
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        ar[0][mb] = r0[mb];
+        ar[1][mb] = r1[mb];
+      }
+    }
+    if (more) lstore(buf ^ 1);
     __syncthreads();
+  }
+
+  if constexpr (KS > 1) {
+    // sum the k-groups' partial tiles through LDS, one m-block per round (the
+    // staging buffers are free: the loop ended on a barrier); group 0 then owns
+    // the epilogue
+    float* red = xs;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      if (mb > 0) __syncthreads();
+      if (kg > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[((((kg - 1) * WN + wn) * NB + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[mb][nb][r] += red[((((g - 1) * WN + wn) * NB + nb) * 16 + r) * 64 + lane];
+      }
+    }
+    if (kg > 0) return;
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -204,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int t = t0 + (wave * NB + nb) * 32 + col;
+        const int t = t0 + (wn * NB + nb) * 32 + col;
         if (t >= Lout) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -234,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // first half (tanh / m), block 1 the matching rows of the second half.
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const int t = t0 + (wave * NB + nb) * 32 + col;
+      const int t = t0 + (wn * NB + nb) * 32 + col;
       if (t >= Lout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -262,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int q = t0 + (wave * NB + nb) * 32 + col;
+        const int q = t0 + (wn * NB + nb) * 32 + col;
         if (q >= n_len) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -449,34 +450,45 @@ struct ProfScope {
   }
 };
 
-template <int K, int CI_C, int MB, int NB, int HALO, int EPI>
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
 static void launch_conv_inst(hipStream_t s, dim3 grid, const ConvArgs& a) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, CI_C, MB, NB, HALO, EPI>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, CI_C, MB, NB, WN, KS, HALO, EPI>), grid, dim3(64 * WN * KS), 0, s, a);
 }
 
-// per-tap-count tile parameters: staged channels per chunk and LDS halo capacity
+// LDS halo capacity per tap count (max (K-1)*dilation the reference configs need)
 template <int K> struct ConvCfg;
-template <> struct ConvCfg<1> { static constexpr int CI = 32, HALO = 0; };
-template <> struct ConvCfg<2> { static constexpr int CI = 32, HALO = 4; };
-template <> struct ConvCfg<3> { static constexpr int CI = 16, HALO = 12; };
-template <> struct ConvCfg<5> { static constexpr int CI = 16, HALO = 24; };
-template <> struct ConvCfg<7> { static constexpr int CI = 16, HALO = 72; };
-template <> struct ConvCfg<11> { static constexpr int CI = 16, HALO = 52; };
+template <> struct ConvCfg<1> { static constexpr int HALO = 0; };
+template <> struct ConvCfg<2> { static constexpr int HALO = 4; };
+template <> struct ConvCfg<3> { static constexpr int HALO = 12; };
+template <> struct ConvCfg<5> { static constexpr int HALO = 24; };
+template <> struct ConvCfg<7> { static constexpr int HALO = 72; };
+template <> struct ConvCfg<11> { static constexpr int HALO = 52; };
+
+// Tile shapes (all 512 threads):
+//   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (GlowTTS, stage 0 at batch 1)
+//   NB1   : 4 time-waves x 2 k-groups, 128 columns
+//   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2 };
+static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
-static int launch_conv_k(hipStream_t s, int MB, int NB, dim3 grid, const ConvArgs& a) {
-  constexpr int CI = ConvCfg<K>::CI, HALO = ConvCfg<K>::HALO;
+static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvArgs& a) {
+  constexpr int HALO = ConvCfg<K>::HALO;
+  constexpr int CI_BIG = (K <= 5) ? 32 : 16;
   if ((K - 1) * a.dil > HALO) return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
-  if (MB == 2 && NB == 1) launch_conv_inst<K, CI, 2, 1, HALO, EPI>(s, grid, a);
-  else if (MB == 2 && NB == 2) launch_conv_inst<K, CI, 2, 2, HALO, EPI>(s, grid, a);
-  else if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
-    if (MB == 1 && NB == 1) launch_conv_inst<K, CI, 1, 1, HALO, EPI>(s, grid, a);
-    else if (MB == 1 && NB == 2) launch_conv_inst<K, CI, 1, 2, HALO, EPI>(s, grid, a);
-    else return fail(MI355TTS_ERR_INVALID, "bad conv tile MB=%d NB=%d", MB, NB);
-  } else {
-    return fail(MI355TTS_ERR_INVALID, "bad conv tile MB=%d NB=%d", MB, NB);
+  if (MB == 2) {
+    if (shape == TILE_SMALL) launch_conv_inst<K, 32, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
+    return 0;
   }
-  return 0;
+  if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
+    if (shape == TILE_SMALL) launch_conv_inst<K, 32, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
+    return 0;
+  }
+  return fail(MI355TTS_ERR_INVALID, "paired epilogue needs MB == 2");
 }
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
@@ -490,10 +502,23 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   a.rows = c.rows;
   const int MB = c.MB;
   const int ytiles = c.mtiles / MB;
-  // NB = 2 (256-column tiles) only when that still leaves >= 2 workgroups per CU
-  int NB = 1;
-  if ((long long)((n_max + 255) / 256) * ytiles * B >= 512) NB = 2;
-  const int T_T = 128 * NB;
+  // tile shape by how many workgroups the launch yields (256 CUs)
+  const long long t128 = (long long)((n_max + 127) / 128) * ytiles * B;
+  const long long t256 = (long long)((n_max + 255) / 256) * ytiles * B;
+  int shape = TILE_NB1;
+  if (t256 >= 768) shape = TILE_NB2;
+  else if (t128 < 384) shape = TILE_SMALL;
+  {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
+    static const int forced = [] {
+      const char* e = std::getenv("MI355TTS_FORCE_TILE");
+      return e ? std::atoi(e) : -1;
+    }();
+    int f = forced;
+    if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
+    if (g_pin_tile >= 0) f = g_pin_tile;
+    if (f >= TILE_SMALL && f <= TILE_NB2) shape = f;
+  }
+  const int T_T = shape == TILE_SMALL ? 64 : (shape == TILE_NB1 ? 128 : 256);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   ProfScope ps(ctx, w, cls, flop);
@@ -501,27 +526,27 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   int rc = 0;
   if (epi == EPI_LINEAR) {
     switch (c.K) {
-      case 1: rc = launch_conv_k<1, EPI_LINEAR>(s, MB, NB, grid, a); break;
-      case 3: rc = launch_conv_k<3, EPI_LINEAR>(s, MB, NB, grid, a); break;
-      case 5: rc = launch_conv_k<5, EPI_LINEAR>(s, MB, NB, grid, a); break;
-      case 7: rc = launch_conv_k<7, EPI_LINEAR>(s, MB, NB, grid, a); break;
-      case 11: rc = launch_conv_k<11, EPI_LINEAR>(s, MB, NB, grid, a); break;
+      case 1: rc = launch_conv_k<1, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 3: rc = launch_conv_k<3, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 5: rc = launch_conv_k<5, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 7: rc = launch_conv_k<7, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 11: rc = launch_conv_k<11, EPI_LINEAR>(s, MB, shape, grid, a); break;
       default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d", c.K);
     }
   } else if (epi == EPI_GATE) {
     switch (c.K) {
-      case 3: rc = launch_conv_k<3, EPI_GATE>(s, MB, NB, grid, a); break;
-      case 5: rc = launch_conv_k<5, EPI_GATE>(s, MB, NB, grid, a); break;
+      case 3: rc = launch_conv_k<3, EPI_GATE>(s, MB, shape, grid, a); break;
+      case 5: rc = launch_conv_k<5, EPI_GATE>(s, MB, shape, grid, a); break;
       default: rc = fail(MI355TTS_ERR_INVALID, "unsupported WaveNet kernel size %d", c.K);
     }
   } else if (epi == EPI_COUPLING) {
-    if (c.K == 1) rc = launch_conv_k<1, EPI_COUPLING>(s, MB, NB, grid, a);
+    if (c.K == 1) rc = launch_conv_k<1, EPI_COUPLING>(s, MB, shape, grid, a);
     else rc = fail(MI355TTS_ERR_INVALID, "coupling conv must be 1x1");
   } else {
     switch (c.K) {
-      case 1: rc = launch_conv_k<1, EPI_UPSAMPLE>(s, MB, NB, grid, a); break;
-      case 2: rc = launch_conv_k<2, EPI_UPSAMPLE>(s, MB, NB, grid, a); break;
-      case 3: rc = launch_conv_k<3, EPI_UPSAMPLE>(s, MB, NB, grid, a); break;
+      case 1: rc = launch_conv_k<1, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
+      case 2: rc = launch_conv_k<2, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
+      case 3: rc = launch_conv_k<3, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
       default: rc = fail(MI355TTS_ERR_INVALID, "unsupported upsample taps %d", c.K);
     }
   }
@@ -1582,6 +1607,68 @@ extern "C" int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int 
 extern "C" int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const float* w,
                                             const float* bias, int Cout, int K, int stride, float in_slope, float* y) {
   return op_conv_common(ctx, x, B, Cin, L, nullptr, w, bias, Cout, K, stride, in_slope, 0, y, true);
+}
+
+extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, int dilation, int L,
+                                     int tile_shape, int iters, float* ms_per_launch) {
+  if (!ctx || !ms_per_launch || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0 || iters <= 0 || !(K % 2))
+    return fail(MI355TTS_ERR_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  std::vector<float> wh((size_t)Cout * Cin * K), bh(Cout), xh((size_t)B * Cin * L);
+  uint32_t st = 12345u;
+  auto rnd = [&]() {
+    st = st * 1664525u + 1013904223u;
+    return ((st >> 8) * (1.0f / 16777216.0f)) * 2.0f - 1.0f;
+  };
+  const float sc = 1.0f / std::sqrt((float)Cin * K);
+  for (auto& v : wh) v = rnd() * sc;
+  for (auto& v : bh) v = rnd();
+  for (auto& v : xh) v = rnd();
+  ArenaBuilder ab;
+  DevConv c = add_conv(ab, wh.data(), bh.data(), Cout, Cin, K, ROWS_PLAIN);
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  Carver cv;
+  const size_t o_w = cv.take(ab.host.size() * sizeof(float));
+  const size_t o_x = cv.take(sizeof(float) * xh.size());
+  const size_t o_y = cv.take(sizeof(float) * (size_t)B * Cout * L);
+  CHECK(reserve(w, cv.pos));
+  char* base = w->arena;
+  float* dw = (float*)(base + o_w);
+  float* dx = (float*)(base + o_x);
+  float* dy = (float*)(base + o_y);
+  hipStream_t s = w->stream;
+  HIPCHECK(hipMemcpyAsync(dw, ab.host.data(), ab.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(dx, xh.data(), sizeof(float) * xh.size(), hipMemcpyHostToDevice, s));
+  fix(c, dw);
+  ConvArgs a = base_args(dx, (long long)Cin * L, L, nullptr, 1, dy, (long long)Cout * L, L, nullptr, 1, dilation,
+                         (K * dilation - dilation) / 2);
+  a.in_const = L;
+  a.out_const = L;
+  a.in_slope = 0.1f;
+  const bool prof = ctx->profiling;
+  ctx->profiling = false;
+  g_pin_tile = tile_shape;
+  int rc = 0;
+  for (int i = 0; i < 3 && !rc; ++i) rc = launch_conv(ctx, w, c, a, EPI_LINEAR, B, L, KC_RESBLOCK);
+  hipEvent_t e0, e1;
+  if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(MI355TTS_ERR_HIP, "hipEventCreate");
+  if (!rc) {
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(ctx, w, c, a, EPI_LINEAR, B, L, KC_RESBLOCK);
+    hipEventRecord(e1, s);
+    hipError_t e = hipStreamSynchronize(s);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "bench_conv1d: %s", hipGetErrorString(e));
+    *ms_per_launch = ms / (float)iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  g_pin_tile = -1;
+  ctx->profiling = prof;
+  return rc;
 }
 
 // ------------------------------------------------------------------ measurement

@@ -20,12 +20,14 @@ struct PackedConv {
 // `rowmap(v)` gives the logical output channel of virtual row v, or -1 for a
 // padding row.  `wget(co, ci, k)` reads the logical weight.
 template <typename RowMap, typename WGet, typename BGet>
-inline PackedConv pack_conv(int vrows, int m_align_tiles, int Cin, int K, RowMap rowmap, WGet wget, BGet bget, bool has_bias) {
+inline PackedConv pack_conv(int vrows, int m_align_tiles, int Cin, int K, RowMap rowmap, WGet wget, BGet bget, bool has_bias,
+                            int oct_align = 4) {
   PackedConv p;
   int mt = (vrows + 31) / 32;
   mt = ((mt + m_align_tiles - 1) / m_align_tiles) * m_align_tiles;
   p.mtiles = mt;
   p.noct = (Cin + 7) / 8;
+  p.noct = ((p.noct + oct_align - 1) / oct_align) * oct_align;  // whole staged chunks only (zero weights)
   p.K = K;
   p.rows = vrows;
   p.Cin = Cin;

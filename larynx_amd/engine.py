@@ -246,6 +246,12 @@ class Engine:
         )
         return y
 
+    def bench_conv1d(self, B, Cin, Cout, K, dilation, L, tile_shape=-1, iters=20) -> float:
+        """Average ms per launch of the conv kernel on device-resident random data."""
+        ms = C.c_float()
+        ffi.check(self.lib, self.lib.mi355tts_bench_conv1d(self._ctx, B, Cin, Cout, K, dilation, L, tile_shape, iters, C.byref(ms)))
+        return float(ms.value)
+
     # ---- measurement -------------------------------------------------------------
     def set_profiling(self, on: bool):
         ffi.check(self.lib, self.lib.mi355tts_set_profiling(self._ctx, 1 if on else 0))

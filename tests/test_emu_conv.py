@@ -50,3 +50,29 @@ def test_conv_transpose1d_matches_oracle(emu_engine, Cin, Cout, K, u, L):
     ref = nn_np.conv_transpose1d(nn_np.leaky_relu(x[0], 0.1), w, b, stride=u, padding=(K - u) // 2)
     assert y.shape[2] == ref.shape[1] == L * u
     np.testing.assert_allclose(y[0], ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("Cin,Cout,K,dil,L", [(24, 40, 3, 3, 300), (16, 16, 11, 5, 520), (40, 33, 1, 1, 290), (16, 72, 7, 1, 300)])
+def test_conv1d_every_tile_shape(emu_engine, monkeypatch, shape, Cin, Cout, K, dil, L):
+    """The launcher picks the tile shape from the problem size; pin each one."""
+    monkeypatch.setenv("MI355TTS_FORCE_TILE_DYNAMIC", str(shape))
+    rng = np.random.default_rng(shape * 7 + K)
+    x = rng.standard_normal((1, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = emu_engine.conv1d(x, w, b, dilation=dil, in_slope=0.1)
+    ref = nn_np.conv1d(nn_np.leaky_relu(x[0], 0.1), w, b, dilation=dil, padding=(K * dil - dil) // 2)
+    np.testing.assert_allclose(y[0], ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_conv_transpose1d_every_tile_shape(emu_engine, monkeypatch, shape):
+    monkeypatch.setenv("MI355TTS_FORCE_TILE_DYNAMIC", str(shape))
+    rng = np.random.default_rng(shape)
+    x = rng.standard_normal((1, 24, 300)).astype(np.float32)
+    w = (rng.standard_normal((24, 12, 16)) / 7).astype(np.float32)
+    b = rng.standard_normal(12).astype(np.float32)
+    y = emu_engine.conv_transpose1d(x, w, b, stride=8, in_slope=0.1)
+    ref = nn_np.conv_transpose1d(nn_np.leaky_relu(x[0], 0.1), w, b, stride=8, padding=4)
+    np.testing.assert_allclose(y[0], ref, rtol=1e-5, atol=2e-5)

@@ -49,6 +49,19 @@ def test_conv1d_kernel(gpu_engine, Cin, Cout, K, dil, L, B, slope, act):
         assert np.all(y[i, :, n:] == 0)
 
 
+@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("Cin,Cout,K,dil,L", [(128, 128, 11, 5, 3000), (192, 384, 5, 1, 478), (64, 64, 7, 3, 9000), (80, 512, 7, 1, 700), (32, 32, 3, 5, 20000), (192, 80, 1, 1, 120)])
+def test_conv1d_every_tile_shape(gpu_engine, monkeypatch, shape, Cin, Cout, K, dil, L):
+    monkeypatch.setenv("MI355TTS_FORCE_TILE_DYNAMIC", str(shape))
+    rng = np.random.default_rng(shape * 7 + K)
+    x = rng.standard_normal((1, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = gpu_engine.conv1d(x, w, b, dilation=dil, in_slope=0.1)
+    ref = nn_np.conv1d(nn_np.leaky_relu(x[0], 0.1), w, b, dilation=dil, padding=(K * dil - dil) // 2)
+    np.testing.assert_allclose(y[0], ref, rtol=1e-4, atol=5e-5)
+
+
 @pytest.mark.parametrize("Cin,Cout,K,u,L", [(16, 8, 16, 8, 50), (512, 256, 16, 8, 624), (64, 32, 4, 2, 5000)])
 def test_conv_transpose1d_kernel(gpu_engine, Cin, Cout, K, u, L):
     rng = np.random.default_rng(K * 100 + u)
