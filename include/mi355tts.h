@@ -156,6 +156,10 @@ int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, in
  * call's own stream and accumulated per kernel class.  `mi355tts_profile_json`
  * writes {"class": {"launches": n, "ms": t, "flop": f}, ...}. */
 int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
+/* options: "serial_branches" (0/1) — run the three MRF ResBlock chains of a
+ * HiFi-GAN stage one after another on one stream instead of concurrently on
+ * three (used when timing single kernels). */
+int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
 

@@ -34,8 +34,13 @@ enum ConvEpilogue {
 enum OutAct { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
 struct ConvArgs {
-  // input activations [B][Cin][x_ld]
+  // input activations [B][Cin][x_ld]; optional x2/x3 of the same geometry are
+  // summed in on load and the sum divided by in_div (the MRF average
+  // xs / num_kernels of hifi_gan/models.py:191-197, taken by the consumer)
   const float* x;
+  const float* x2;
+  const float* x3;
+  float in_div;
   long long x_bs;
   int x_ld;
   // valid input length per batch row: in_len ? in_len[b] * in_mul : in_const
@@ -118,20 +123,25 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int roww = T_T + (K - 1) * a.dil;  // staged columns actually used
   const float slope = a.in_slope;
   const float* xb = a.x + (long long)b * a.x_bs;
+  const float* xb2 = a.x2 ? a.x2 + (long long)b * a.x_bs : nullptr;
+  const float* xb3 = a.x3 ? a.x3 + (long long)b * a.x_bs : nullptr;
   const int nchunks = a.noct / OCTS;  // noct is padded to a multiple of OCTS at pack time
 
   // ---- staging of the activation tile (global -> VGPR -> LDS), branch-free:
   // every lane loads from a clamped in-range address and zeroes by select, so the
   // loads issue back to back instead of one exec-masked branch each.
-  float pre[NR * NC];
+  // Two register sets: the tile for chunk c+2 is requested while chunk c computes,
+  // so a staged chunk has two MFMA phases (not one) to cover the L2/MALL latency.
+  float preA[NR * NC], preB[NR * NC];
   const int cin_last = a.Cin - 1;
   const int lin_last = Lin - 1;
-  auto gload = [&](int chunk) {
+  auto gload = [&](int chunk, float (&pre)[NR * NC]) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int ci = chunk * CI_C + ty + NWAVES * i;
       const bool row_ok = ci < a.Cin;
-      const float* xr = xb + (long long)(row_ok ? ci : cin_last) * a.x_ld;
+      const long long roff = (long long)(row_ok ? ci : cin_last) * a.x_ld;
+      const float* xr = xb + roff;
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int cc = tx + 64 * j;
@@ -139,13 +149,18 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
         const bool ok = row_ok && cc < roww && ti >= 0 && ti < Lin;
         const int tc = ti < 0 ? 0 : (ti > lin_last ? lin_last : ti);
         float v = xr[tc];
+        if (xb2) {  // wave-uniform
+          v += xb2[roff + tc];
+          if (xb3) v += xb3[roff + tc];
+          v = v / a.in_div;
+        }
         v = ok ? v : 0.f;
         v = v > 0.f ? v : v * slope;
         pre[i * NC + j] = v;
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const float (&pre)[NR * NC]) {
     float* dst = xs + buf * (CI_C * XW);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -187,8 +202,9 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     return (long long)(((chunk * OCTS + kg + oi * KS) * K + k)) * 64;
   };
 
-  gload(0);
-  lstore(0);
+  gload(0, preA);
+  if (nchunks > 1) gload(1, preB);
+  lstore(0, preA);
   __syncthreads();
 
   // 3-deep register ring of A fragments: step q uses ar[q % 3] while the loads
@@ -202,10 +218,10 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
 
   const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31);
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  auto do_chunk = [&](int chunk, float (&pre_load)[NR * NC], const float (&pre_store)[NR * NC]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
-    if (more) gload(chunk + 1);
+    if (chunk + 2 < nchunks) gload(chunk + 2, pre_load);
     const float* xt = xs + buf * (CI_C * XW) + b_off + kg * 8 * XW;
     float bcur[4][NB], bnxt[4][NB];
 #pragma unroll
@@ -259,8 +275,12 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
         ar[1][mb] = r1[mb];
       }
     }
-    if (more) lstore(buf ^ 1);
+    if (more) lstore(buf ^ 1, pre_store);
     __syncthreads();
+  };
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    do_chunk(chunk, preA, preB);
+    if (chunk + 1 < nchunks) do_chunk(chunk + 1, preB, preA);
   }
 
   if constexpr (KS > 1) {
@@ -293,71 +313,135 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   }
 
   // ---------------------------------------------------------------- epilogue
-  // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Loads (bias / residual / accumulate) go out in batches of 16 from clamped,
+  // always-valid addresses under wave-uniform conditions only; lanes outside the
+  // tensor just skip the store.  (One exec-masked branch per element would cost a
+  // full memory round trip per element.)
   const int col = lane & 31;
   const int rbase = 4 * (lane >> 5);
 
   if constexpr (EPI == EPI_LINEAR) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+      const int row0 = (mt0 + mb) * 32 + rbase;
+      const bool first = (mt0 + mb) * 32 < a.split;  // split is a multiple of 32 (or 0 / >= rows)
+      float* yp = first ? a.y : a.y2;
+      const long long ybs = first ? a.y_bs : a.y2_bs;
+      const int yld = first ? a.y_ld : a.y2_ld;
+      const int rowoff = first ? 0 : a.split;
+      const float* rp = first ? a.res : nullptr;
+      const bool acc_on = first ? (a.accum != 0) : (a.accum2 != 0);
+      const float alpha = first ? a.alpha : 1.0f;
+      const int act = first ? a.out_act : (int)ACT_NONE;
+      float bb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        bb[r] = a.bias ? a.bias[row] : 0.f;  // packed bias is padded to whole m-tiles
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int t = t0 + (wn * NB + nb) * 32 + col;
-        if (t >= Lout) continue;
+        const bool tok = t < Lout;
+        const int tc = tok ? t : Lout - 1;
+        float* yb = yp + (long long)b * ybs + tc;
+        const float* rb = rp ? rp + (long long)b * ybs + tc : nullptr;
+        int off[16];
+        bool ok[16];
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-          if (row >= a.rows) continue;
-          float v = acc[mb][nb][r];
-          if (a.bias) v += a.bias[row];
-          if (row < a.split) {
-            const long long o = (long long)b * a.y_bs + (long long)row * a.y_ld + t;
-            if (a.res) v += a.res[o];
-            v *= a.alpha;
-            if (a.accum) v += a.y[o];
-            if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (a.out_act == ACT_TANH) v = tanhf(v);
-            a.y[o] = v;
-          } else {
-            const long long o = (long long)b * a.y2_bs + (long long)(row - a.split) * a.y2_ld + t;
-            if (a.accum2) v += a.y2[o];
-            a.y2[o] = v;
-          }
+          const int row = row0 + (r & 3) + 8 * (r >> 2);
+          const bool rok = row < a.rows;
+          ok[r] = rok && tok;
+          off[r] = ((rok ? row : a.rows - 1) - rowoff) * yld;
+          v[r] = acc[mb][nb][r] + bb[r];
         }
+        if (rb) {
+          float rv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += rv[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= alpha;
+        if (acc_on) {
+          float ov[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ov[r] = yb[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += ov[r];
+        }
+        if (act == ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        } else if (act == ACT_TANH) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok[r]) yb[off[r]] = v[r];
       }
     }
   } else if constexpr (EPI == EPI_GATE || EPI == EPI_COUPLING) {
     static_assert(MB == 2, "paired epilogues need MB == 2");
     // virtual tile pair p = blockIdx.y: block 0 holds rows c = p*32 + i of the
     // first half (tanh / m), block 1 the matching rows of the second half.
+    float b0[16], b1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + rbase;
+      b0[r] = a.bias ? a.bias[mt0 * 32 + i] : 0.f;
+      b1[r] = a.bias ? a.bias[(mt0 + 1) * 32 + i] : 0.f;
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int t = t0 + (wn * NB + nb) * 32 + col;
-      if (t >= Lout) continue;
+      const bool tok = t < Lout;
+      const int tc = tok ? t : Lout - 1;
+      float* yb = a.y + (long long)b * a.y_bs + tc;
+      int off[16];
+      bool ok[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + rbase;
-        const int c = blockIdx.y * 32 + i;
-        if (c >= a.half) continue;
-        float v0 = acc[0][nb][r];
-        float v1 = acc[MB - 1][nb][r];
-        if (a.bias) {
-          v0 += a.bias[mt0 * 32 + i];
-          v1 += a.bias[(mt0 + 1) * 32 + i];
-        }
-        const long long o = (long long)b * a.y_bs + (long long)c * a.y_ld + t;
-        float out;
-        if constexpr (EPI == EPI_GATE) {
-          out = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
-        } else {
-          out = (a.res[o] - v0) * expf(-v1);
-        }
-        a.y[o] = out;
+        const int c = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        const bool cok = c < a.half;
+        ok[r] = cok && tok;
+        off[r] = (cok ? c : a.half - 1) * a.y_ld;
       }
+      float out[16];
+      if constexpr (EPI == EPI_GATE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v0 = acc[0][nb][r] + b0[r];
+          const float v1 = acc[1][nb][r] + b1[r];
+          out[r] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
+        }
+      } else {
+        const float* rb = a.res + (long long)b * a.y_bs + tc;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v0 = acc[0][nb][r] + b0[r];
+          const float v1 = acc[1][nb][r] + b1[r];
+          out[r] = (rv[r] - v0) * expf(-v1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok[r]) yb[off[r]] = out[r];
     }
   } else {  // EPI_UPSAMPLE
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+      float bb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[r] = a.bias ? a.bias[(mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase] : 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int q = t0 + (wn * NB + nb) * 32 + col;
@@ -370,9 +454,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
           const int ph = row - co * a.up;
           const int n = q * a.up + ph - a.up_pad;
           if (n < 0 || n >= Lout) continue;
-          float v = acc[mb][nb][r];
-          if (a.bias) v += a.bias[row];
-          a.y[(long long)b * a.y_bs + (long long)co * a.y_ld + n] = v;
+          a.y[(long long)b * a.y_bs + (long long)co * a.y_ld + n] = acc[mb][nb][r] + bb[r];
         }
       }
     }

@@ -86,7 +86,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
     p = pack_conv(
         Cout, d.MB, Cin, K, [&](int v) { return v; },
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
-        d.has_bias);
+        d.has_bias, K == 1 ? 8 : 4);
   } else if (layout == ROWS_PAIR) {
     // virtual tiles (2p, 2p+1) = rows [32p, 32p+32) of the first and second half
     const int half = half_or_up;
@@ -101,7 +101,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
           return (tile & 1) * half + c;
         },
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
-        d.has_bias);
+        d.has_bias, K == 1 ? 8 : 4);
   } else {
     // ConvTranspose1d(Cin, Cout, Ku, stride u, padding (Ku-u)/2) as a Kt = Ku/u tap
     // conv over q with virtual rows v = co*u + r:
@@ -118,7 +118,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
           const int m = Kt - 1 - k;
           return w[((size_t)ci * Cout + co) * Ku + m * u + r];
         },
-        [&](int v) { return bias[v / u]; }, d.has_bias);
+        [&](int v) { return bias[v / u]; }, d.has_bias, Kt == 1 ? 8 : 4);
   }
   d.mtiles = p.mtiles;
   d.noct = p.noct;
@@ -309,6 +309,10 @@ struct Worker {
   size_t pinned_ints = 0;
   std::vector<ProfEvent> events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+  // side streams for the independent MRF branches of a HiFi-GAN stage
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_join[2] = {nullptr, nullptr};
 };
 
 struct mi355tts_ctx {
@@ -320,6 +324,7 @@ struct mi355tts_ctx {
   std::vector<Worker*> free_workers;
   std::vector<Worker*> all_workers;
   bool profiling = false;
+  bool serial_branches = false;
   struct Acc {
     long long launches = 0;
     double ms = 0, flop = 0;
@@ -427,7 +432,9 @@ struct ProfScope {
   Worker* w;
   bool on;
   ProfEvent ev;
-  ProfScope(mi355tts_ctx* c, Worker* wk, int cls, double flop) : ctx(c), w(wk), on(c->profiling) {
+  hipStream_t st;
+  ProfScope(mi355tts_ctx* c, Worker* wk, int cls, double flop, hipStream_t stream = nullptr)
+      : ctx(c), w(wk), on(c->profiling), st(stream ? stream : wk->stream) {
     if (!on) return;
     if (!w->event_pool.empty()) {
       ev.a = w->event_pool.back().first;
@@ -441,11 +448,11 @@ struct ProfScope {
     }
     ev.cls = cls;
     ev.flop = flop;
-    hipEventRecord(ev.a, w->stream);
+    hipEventRecord(ev.a, st);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(ev.b, w->stream);
+    hipEventRecord(ev.b, st);
     w->events.push_back(ev);
   }
 };
@@ -474,16 +481,17 @@ static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 template <int K, int EPI>
 static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvArgs& a) {
   constexpr int HALO = ConvCfg<K>::HALO;
-  constexpr int CI_BIG = (K <= 5) ? 32 : 16;
+  constexpr int CI_BIG = (K == 1) ? 64 : (K <= 5) ? 32 : 16;
+  constexpr int CI_SMALL = (K == 1) ? 64 : 32;
   if ((K - 1) * a.dil > HALO) return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
   if (MB == 2) {
-    if (shape == TILE_SMALL) launch_conv_inst<K, 32, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
+    if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
-    if (shape == TILE_SMALL) launch_conv_inst<K, 32, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
+    if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
@@ -493,8 +501,11 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
 // template instance.  n_max = largest GEMM-N extent over the batch rows.
-static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls) {
+static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
+                       hipStream_t stream = nullptr) {
   if (n_max <= 0 || B <= 0) return 0;
+  if (epi == EPI_LINEAR && a.split > 0 && a.split < c.rows && (a.split % 32))
+    return fail(MI355TTS_ERR_INVALID, "row split %d must be a multiple of 32", a.split);
   a.w = c.w;
   a.bias = c.has_bias ? c.bias : nullptr;
   a.noct = c.noct;
@@ -521,8 +532,8 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   const int T_T = shape == TILE_SMALL ? 64 : (shape == TILE_NB1 ? 128 : 256);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
-  ProfScope ps(ctx, w, cls, flop);
-  hipStream_t s = w->stream;
+  hipStream_t s = stream ? stream : w->stream;
+  ProfScope ps(ctx, w, cls, flop, s);
   int rc = 0;
   if (epi == EPI_LINEAR) {
     switch (c.K) {
@@ -621,6 +632,11 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
       hipEventDestroy(p.first);
       hipEventDestroy(p.second);
     }
+    for (int i = 0; i < 2; ++i) {
+      if (w->aux[i]) hipStreamDestroy(w->aux[i]);
+      if (w->ev_join[i]) hipEventDestroy(w->ev_join[i]);
+    }
+    if (w->ev_fork) hipEventDestroy(w->ev_fork);
     if (w->arena) hipFree(w->arena);
     if (w->pinned) hipHostFree(w->pinned);
     if (w->stream) hipStreamDestroy(w->stream);
@@ -1075,8 +1091,12 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
 // ------------------------------------------------------------------ GlowTTS forward
 static int run_layernorm(Worker* w, const float* x, const float* res, const float* g, const float* b, float* y, int C,
                          long long bs, int ld, const int* len, int B, int Pmax, int post_relu) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((Pmax + 63) / 64, B), dim3(256), 0, w->stream, x, res, g, b, y, C, bs, ld, len, 0,
-                     post_relu, 1e-4f);
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, x, res, g, b, y, C, bs, ld, len, 0,
+                       post_relu, 1e-4f);
+  else
+    hipLaunchKernelGGL(layernorm_kernel, dim3((Pmax + 63) / 64, B), dim3(256), 0, w->stream, x, res, g, b, y, C, bs, ld, len, 0,
+                       post_relu, 1e-4f);
   return 0;
 }
 
@@ -1412,40 +1432,61 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
   }
   const size_t Nld = (size_t)((N + 3) & ~3LL);
+  const int nk = h.num_kernels;
+  // The nk ResBlock chains of a stage are independent (MRF): run them on separate
+  // streams so their workgroups interleave — at batch 1 one conv launch has fewer
+  // tiles than the chip has SIMDs.  Each chain writes its own output; the average
+  // is taken by the consumer's staging load.
+  const bool concurrent = !ctx->serial_branches && nk >= 2 && nk <= 3;
+  if (concurrent && !w->aux[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIPCHECK(hipStreamCreateWithFlags(&w->aux[i], hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&w->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+  }
+  const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
-  size_t o_buf[6];
-  for (int i = 0; i < 6; ++i) o_buf[i] = cv.take(sizeof(float) * (size_t)B * plane);
+  size_t o_buf[16];
+  for (int i = 0; i < nbuf; ++i) o_buf[i] = cv.take(sizeof(float) * (size_t)B * plane);
   const size_t o_wav = cv.take(sizeof(float) * (size_t)B * Nld);
   const size_t o_i16 = cv.take(sizeof(short) * (size_t)B * Nld);
   const size_t o_peak = cv.take(sizeof(unsigned) * B);
   CHECK(reserve(w, cv.pos));
   char* base = w->arena;
-  float* buf[6];
-  for (int i = 0; i < 6; ++i) buf[i] = (float*)(base + o_buf[i]);
+  float* buf[16];
+  for (int i = 0; i < nbuf; ++i) buf[i] = (float*)(base + o_buf[i]);
   float* wav = (float*)(base + o_wav);
   short* i16 = (short*)(base + o_i16);
   unsigned* peak = (unsigned*)(base + o_peak);
   const int* d_frames = mel->frames_dev;
 
-  float* cur = buf[0];  // stage input
+  // stage input: `cur[0]` alone, or the nk chain outputs cur[0..nk) still to be averaged
+  float* cur[3] = {buf[0], nullptr, nullptr};
+  int ncur = 1;
   float* xu = buf[1];
-  float* tb = buf[2];
-  float* pa = buf[3];
-  float* pb = buf[4];
-  float* sum = buf[5];
   {  // conv_pre (models.py:187)
-    ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur, (long long)C0 * F, F, d_frames, 1, 1, 3);
+    ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * F, F, d_frames, 1, 1, 3);
     CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO));
   }
+  auto set_inputs = [&](ConvArgs& a) {
+    if (ncur > 1) {
+      a.x2 = cur[1];
+      a.x3 = ncur > 2 ? cur[2] : nullptr;
+      a.in_div = (float)ncur;
+    }
+  };
   int mul = 1;
   int Lin = F;
   int ch = C0;
+  int flip = 0;  // which half of the chain-output buffers this stage writes
   for (int i = 0; i < h.num_upsamples; ++i) {
     const int u = h.upsample_rates[i], ku = h.upsample_kernel_sizes[i];
     const int cout = C0 >> (i + 1);
     const int Lout = Lin * u;
     {  // x = ups[i](leaky_relu(x, 0.1))  (models.py:189-190)
-      ConvArgs a = base_args(cur, (long long)ch * Lin, Lin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
+      ConvArgs a = base_args(cur[0], (long long)ch * Lin, Lin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
+      set_inputs(a);
       a.in_slope = 0.1f;
       a.up = u;
       a.up_pad = (ku - u) / 2;
@@ -1454,44 +1495,79 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     mul *= u;
     ch = cout;
     const long long bs = (long long)ch * Lout;
-    const float inv_nk = 1.0f / (float)h.num_kernels;
-    for (int j = 0; j < h.num_kernels; ++j) {  // MRF: sum of resblocks / num_kernels (models.py:191-197)
+    const float inv_nk = 1.0f / (float)nk;
+    if (concurrent) {
+      HIPCHECK(hipEventRecord(w->ev_fork, s));
+      for (int j = 1; j < nk; ++j) HIPCHECK(hipStreamWaitEvent(w->aux[j - 1], w->ev_fork, 0));
+    }
+    float* outs[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
       const int kk = h.resblock_kernel_sizes[j];
+      hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
+      float *tb, *pa, *pb, *dst_last;
+      if (concurrent) {
+        // per-chain scratch: buf[2 + 4j .. 2 + 4j + 3] = {t, ping, out(flip 0), out(flip 1)}
+        tb = buf[2 + 4 * j];
+        pa = buf[2 + 4 * j + 1];
+        pb = buf[2 + 4 * j + 2 + (flip ^ 1)];  // last stage's output: dead once the upsampler (before the fork) has read it
+        dst_last = buf[2 + 4 * j + 2 + flip];
+      } else {
+        tb = buf[2];
+        pa = buf[3];
+        pb = buf[4];
+        dst_last = buf[5];
+      }
+      outs[j] = dst_last;
       const float* rin = xu;
       for (int d = 0; d < h.num_dilations; ++d) {
         const HifiResConv& rc = hm->rb[i][j][d];
         const bool last = d == h.num_dilations - 1;
-        float* dst = last ? sum : ((d & 1) ? pb : pa);
+        float* dst = last ? dst_last : ((d & 1) ? pb : pa);
+        if (!dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
         if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
           ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
           c.in_slope = 0.1f;
           c.res = rin;
-          if (last) {
+          if (last && !concurrent) {
             c.alpha = inv_nk;
             c.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK));
+          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
         } else {  // ResBlock2.forward, models.py:136-141
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
           a.res = rin;
-          if (last) {
+          if (last && !concurrent) {
             a.alpha = inv_nk;
             a.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
         }
         rin = dst;
       }
     }
-    std::swap(cur, sum);
+    if (concurrent) {
+      for (int j = 1; j < nk; ++j) {
+        HIPCHECK(hipEventRecord(w->ev_join[j - 1], w->aux[j - 1]));
+        HIPCHECK(hipStreamWaitEvent(s, w->ev_join[j - 1], 0));
+      }
+      for (int j = 0; j < nk; ++j) cur[j] = outs[j];
+      ncur = nk;
+      flip ^= 1;
+    } else {
+      // serial: buf[5] holds the averaged sum; rotate it with the stage-input buffer
+      std::swap(buf[5], buf[0]);
+      cur[0] = buf[0];
+      ncur = 1;
+    }
     Lin = Lout;
   }
   {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
-    ConvArgs a = base_args(cur, (long long)ch * Lin, Lin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
+    ConvArgs a = base_args(cur[0], (long long)ch * Lin, Lin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
+    set_inputs(a);
     a.in_slope = 0.01f;
     a.out_act = ACT_TANH;
     CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO));
@@ -1677,6 +1753,15 @@ extern "C" int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->profiling = enabled != 0;
   return 0;
+}
+extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return fail(MI355TTS_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (std::strcmp(name, "serial_branches") == 0) {
+    ctx->serial_branches = value != 0;
+    return 0;
+  }
+  return fail(MI355TTS_ERR_INVALID, "unknown option '%s'", name);
 }
 extern "C" int mi355tts_profile_reset(mi355tts_ctx* ctx) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");

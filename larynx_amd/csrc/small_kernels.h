@@ -90,6 +90,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
   }
 }
 
+// Fast path for C <= 256: 16 columns x 16 channel groups per workgroup, the
+// column's values live in registers (one global read, one write), group sums
+// meet in LDS.
+__global__ __launch_bounds__(256) void layernorm16_kernel(const float* x, const float* res, const float* gamma,
+                                                          const float* beta, float* y, int C, long long bs, int ld,
+                                                          const int* len, int pre_relu, int post_relu, float eps) {
+  __shared__ float red[16][17];
+  const int b = blockIdx.y;
+  const int tl = threadIdx.x & 15;
+  const int g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + tl;
+  const int L = len[b];
+  const bool valid = t < L;
+  const int tc = valid ? t : (L > 0 ? L - 1 : 0);
+  const float* xb = x + (long long)b * bs + tc;
+  const float* rb = res ? res + (long long)b * bs + tc : nullptr;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = g + 16 * i;
+    const int cc = c < C ? c : C - 1;
+    float u = xb[(long long)cc * ld];
+    if (rb) u += rb[(long long)cc * ld];
+    if (pre_relu) u = fmaxf(u, 0.f);
+    v[i] = c < C ? u : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+  red[g][tl] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mean += red[k][tl];
+  mean /= (float)C;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = (g + 16 * i < C) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  red[g][tl] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) var += red[k][tl];
+  var /= (float)C;
+  const float rstd = rsqrtf(var + eps);
+  if (!valid) return;
+  float* yb = y + (long long)b * bs + t;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = g + 16 * i;
+    if (c < C) {
+      float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (post_relu) o = fmaxf(o, 0.f);
+      yb[(long long)c * ld] = o;
+    }
+  }
+}
+
 // G4: windowed relative-position self-attention (glow_tts/attentions.py:214-264).
 // qkv is [B][3H][ld] (q rows 0..H, k rows H..2H, v rows 2H..3H), head h uses
 // channels h*dk..(h+1)*dk.  One wave per query row i, 4 rows per workgroup:

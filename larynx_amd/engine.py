@@ -256,6 +256,9 @@ class Engine:
     def set_profiling(self, on: bool):
         ffi.check(self.lib, self.lib.mi355tts_set_profiling(self._ctx, 1 if on else 0))
 
+    def set_option(self, name: str, value: int):
+        ffi.check(self.lib, self.lib.mi355tts_set_option(self._ctx, name.encode("ascii"), int(value)))
+
     def profile_reset(self):
         ffi.check(self.lib, self.lib.mi355tts_profile_reset(self._ctx))
 

@@ -100,3 +100,19 @@ def test_errors_are_reported_not_crashed(emu_engine, tiny_models):
     with pytest.raises(Mi355ttsError):  # noise too short for the utterance
         emu_engine.glow_infer(tiny_models["g"], _ids(np.random.default_rng(1), 20), 0.667, 1.0,
                               noise=np.zeros((HP.TINY_GLOW.mel_channels, 4), np.float32))
+
+
+def test_serial_and_concurrent_branches_agree(emu_engine, tiny_models):
+    """The MRF chains run on side streams by default; the single-stream schedule
+    (used when timing single kernels) must give the same waveform."""
+    rng = np.random.default_rng(9)
+    melin = (rng.standard_normal((1, HP.TINY_HIFIGAN.num_mels, 21)) * 2).astype(np.float32)
+    mb = emu_engine.mel_from_numpy(melin)
+    a, _ = emu_engine.hifigan_infer(tiny_models["v"], mb)
+    emu_engine.set_option("serial_branches", 1)
+    try:
+        b, _ = emu_engine.hifigan_infer(tiny_models["v"], mb)
+    finally:
+        emu_engine.set_option("serial_branches", 0)
+    ref = hifi_gan_np.hifigan_infer(tiny_models["vsd"], HP.TINY_HIFIGAN, melin[0])
+    assert np.sqrt(np.mean((a[0] - ref) ** 2)) < 1e-5 and np.sqrt(np.mean((b[0] - ref) ** 2)) < 1e-5

@@ -93,6 +93,18 @@ def test_golden_reference_parity(gpu_engine, name):
     assert np.abs(i16[0][::st].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 2  # 1 LSB + peak round-off
 
 
+def test_serial_branch_schedule_matches_reference(gpu_engine):
+    c = load_case("ljspeech_low_echo")
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    gpu_engine.set_option("serial_branches", 1)
+    try:
+        wav, _ = gpu_engine.hifigan_infer(v, mb)
+    finally:
+        gpu_engine.set_option("serial_branches", 0)
+    assert np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)) <= 2e-5
+
+
 def test_vocoder_alone_on_reference_mel(gpu_engine):
     """`mels_to_audio` drop-in: host mel (already transformed) in, int16 out."""
     c = load_case("ljspeech_high_echo")
