@@ -46,6 +46,9 @@ def cpu_baseline(max_seconds: float = 30.0):
     from larynx_amd.audio import ljspeech_audio_settings
     from oracle import audio_np, glow_tts_np, hifi_gan_np
 
+    from threadpoolctl import threadpool_limits
+
+    threads = min(os.cpu_count() or 1, int(os.environ.get("LARYNX_CPU_BASELINE_THREADS", "32")))
     ids = np.array([3, 8, 4, 14, 3, 35, 3, 26, 4, 34, 22, 3, 1, 3, 19, 4, 32, 23, 3, 35, 19, 3, 4, 37, 16, 20, 3, 2], np.int64)
     gsd = synthetic.make_glow_state_dict(HP.LJSPEECH, seed=1234)
     vsd = synthetic.make_hifigan_state_dict(HP.HIFIGAN_HIGH, seed=1234)
@@ -56,9 +59,10 @@ def cpu_baseline(max_seconds: float = 30.0):
     F = 0
     while len(times) < 3 and (time.perf_counter() - t_all) < max_seconds:
         t0 = time.perf_counter()
-        mel = glow_tts_np.glow_tts_infer(gsd, HP.LJSPEECH, ids, noise, 0.667, 1.0)
-        wav = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_HIGH, audio_np.mel_to_vocoder_input(mel, s))
-        audio_np.audio_float_to_int16(wav)
+        with threadpool_limits(limits=threads):
+            mel = glow_tts_np.glow_tts_infer(gsd, HP.LJSPEECH, ids, noise, 0.667, 1.0)
+            wav = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_HIGH, audio_np.mel_to_vocoder_input(mel, s))
+            audio_np.audio_float_to_int16(wav)
         times.append(time.perf_counter() - t0)
         F = mel.shape[1]
     best = min(times)
@@ -67,11 +71,12 @@ def cpu_baseline(max_seconds: float = 30.0):
     return {
         "value": 1.0 / (rtf * 624 * 256 / SAMPLE_RATE),
         "unit": "utterances/s",
-        "cores": os.cpu_count(),
+        "cores": threads,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "rtf": rtf,
         "x_realtime": 1.0 / rtf,
-        "sample": f"numpy oracle (OpenBLAS, {os.cpu_count()} threads), fixture sentence be_a_voice_not_an_echo: 28 ids -> {F} frames = "
+        "sample": f"numpy oracle (OpenBLAS capped at {threads} threads of {os.cpu_count()} host CPUs), fixture sentence be_a_voice_not_an_echo: 28 ids -> {F} frames = "
                   f"{audio_s:.2f} s audio, min of {len(times)} runs = {best:.2f} s; value = standard 624-frame utterances/s at that RTF",
     }
 

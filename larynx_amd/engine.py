@@ -49,6 +49,10 @@ class MelBatch:
     def shape(self):
         return (self.batch, self.channels, self.max_frames)
 
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy("raw")
+        return a if dtype is None else a.astype(dtype)
+
     def free(self):
         if self._h is not None:
             self._engine.lib.mi355tts_mel_free(self._h)

@@ -1,0 +1,64 @@
+"""HiFi-GAN vocoder on the HIP backend — drop-in for
+`larynx.hifi_gan.HiFiGanVocoder` (`larynx/hifi_gan.py:31-203`)."""
+from __future__ import annotations
+
+import logging
+import typing
+from concurrent.futures import Executor
+
+import numpy as np
+
+from .constants import ARRAY_OR_TENSOR, InferenceBackend, SettingsType, VocoderModel, VocoderModelConfig
+from .engine import MelBatch
+from .hparams import HifiGanHParams
+from .runtime import find_checkpoint, get_engine, read_config
+from .weights import load_state_dict
+
+_LOGGER = logging.getLogger("hifi_gan")
+
+
+class HipHiFiGanVocoder(VocoderModel):
+    """`mels_to_audio(mels, settings)` accepts what the reference accepts — a
+    float32 `[1, 80, F]` array that already went through the AudioSettings
+    transforms (`larynx/hifi_gan.py:145-150`) — or the device-resident `MelBatch`
+    a `HipGlowTextToSpeech` returned, and gives back the same `int16 [N]`
+    (`audio_float_to_int16(...).squeeze()`, :168-169).
+
+    The spectral-subtraction denoiser (`denoiser_strength > 0`, :152-179) is the
+    next row of SURVEY.md §8(f) and not on the HIP path yet: asking for it raises
+    rather than silently skipping it."""
+
+    def __init__(self, config: VocoderModelConfig, executor: typing.Optional[Executor] = None, device: int = 0,
+                 library_path=None, state_dict=None, model_config: typing.Optional[dict] = None):
+        super().__init__(config)
+        if config.backend not in (None, InferenceBackend.HIP):
+            raise ValueError(f"Unknown backend: {config.backend}")
+        if config.half:
+            raise ValueError("the HIP backend computes in fp32 (parity mode); half=True is not supported")
+        self.engine = get_engine(device, library_path)
+        cfg = model_config if model_config is not None else read_config(config.model_path)
+        self.hparams = HifiGanHParams.from_config(cfg)
+        self.mel_channels = self.hparams.num_mels
+        if state_dict is None:
+            ckpt = find_checkpoint(config.model_path)
+            _LOGGER.debug("Loading HiFi-GAN checkpoint from %s", ckpt)
+            state_dict = load_state_dict(ckpt, "generator")
+        self.model_id = self.engine.load_hifigan(self.hparams, state_dict)
+        self.denoiser_strength = float(config.denoiser_strength)
+
+    def mels_to_audio(self, mels: ARRAY_OR_TENSOR, settings: typing.Optional[SettingsType] = None) -> np.ndarray:
+        strength = self.denoiser_strength
+        if settings:
+            strength = float(settings.get("denoiser_strength", strength))
+        if strength > 0:
+            raise NotImplementedError("denoiser_strength > 0 is not available on the HIP backend yet (SURVEY.md §8(f) rank 1)")
+        batch = mels if isinstance(mels, MelBatch) else self.engine.mel_from_numpy(np.asarray(mels, np.float32))
+        _, i16 = self.engine.hifigan_infer(self.model_id, batch, want_float=False, want_int16=True)
+        n = int(batch.frames[0]) * self.engine.hop(self.model_id)
+        return i16[0, :n] if batch.batch == 1 else i16
+
+    def mels_to_float(self, mels: ARRAY_OR_TENSOR) -> np.ndarray:
+        """Generator output before `audio_float_to_int16` (what waveform parity is defined on)."""
+        batch = mels if isinstance(mels, MelBatch) else self.engine.mel_from_numpy(np.asarray(mels, np.float32))
+        f32, _ = self.engine.hifigan_infer(self.model_id, batch, want_float=True, want_int16=False)
+        return f32

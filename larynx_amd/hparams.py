@@ -119,7 +119,9 @@ class HifiGanHParams:
         layout (`{"model": {...}}`, vctk_medium/vctk_small) and the upstream flat
         layout (universal_large/config.json:2-15)."""
         m = cfg["model"] if "model" in cfg else cfg
+        num_mels = int(cfg.get("audio", {}).get("num_mels", cfg.get("num_mels", 80))) if isinstance(cfg.get("audio", {}), dict) else 80
         return HifiGanHParams(
+            num_mels=num_mels,
             resblock=str(m.get("resblock", "1")),
             upsample_rates=tuple(int(v) for v in m["upsample_rates"]),
             upsample_kernel_sizes=tuple(int(v) for v in m["upsample_kernel_sizes"]),
@@ -139,7 +141,8 @@ class HifiGanHParams:
                 "upsample_initial_channel": self.upsample_initial_channel,
                 "resblock_kernel_sizes": list(self.resblock_kernel_sizes),
                 "resblock_dilation_sizes": [list(d) for d in self.resblock_dilation_sizes],
-            }
+            },
+            "audio": {"num_mels": self.num_mels},
         }
 
     @property

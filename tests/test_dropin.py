@@ -1,0 +1,86 @@
+"""The reference-shaped host interface (`larynx_amd.load_tts_model`,
+`load_vocoder_model`, `sentence_task`, `phonemes_to_speech`) over a voice
+directory on disk, on the emulator build."""
+import json
+
+import numpy as np
+import pytest
+
+import larynx_amd
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from larynx_amd.constants import InferenceBackend, TextToSpeechType, VocoderType
+from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+
+@pytest.fixture(scope="module")
+def voice_dirs(tmp_path_factory):
+    root = tmp_path_factory.mktemp("voices")
+    gdir, vdir = root / "tiny-glow_tts", root / "tiny_hifi_gan"
+    gdir.mkdir()
+    vdir.mkdir()
+    gsd = synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=3)
+    vsd = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=3)
+    cfg = HP.TINY_GLOW.to_config()
+    cfg["audio"].update({k: v for k, v in vars(ljspeech_audio_settings()).items() if k != "mel_channels"})
+    (gdir / "config.json").write_text(json.dumps(cfg))
+    vcfg = HP.TINY_HIFIGAN.to_config()
+    vcfg["audio"] = {"num_mels": HP.TINY_HIFIGAN.num_mels}
+    (vdir / "config.json").write_text(json.dumps(vcfg))
+    np.savez(gdir / "generator.npz", **gsd)
+    np.savez(vdir / "generator.npz", **vsd)
+    return gdir, vdir, gsd, vsd
+
+
+def test_models_behave_like_the_reference_classes(emu_library, voice_dirs):
+    gdir, vdir, gsd, vsd = voice_dirs
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, backend=InferenceBackend.HIP, library_path=emu_library)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, backend=InferenceBackend.HIP, library_path=emu_library)
+    # the registry attaches these after construction (larynx/__init__.py:362-363)
+    setattr(tts, "phoneme_to_id", {"_": 0})
+    setattr(tts, "audio_settings", ljspeech_audio_settings())
+    exposed = getattr(tts, "audio_settings")
+    assert not (exposed.signal_norm or exposed.convert_db_to_amp or exposed.do_dynamic_range_compression)
+    assert exposed.sample_rate == 22050
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(2), 13, HP.TINY_GLOW.num_symbols)
+    audio = larynx_amd.sentence_task("hello", ids, exposed, tts, {"noise_scale": 0.0}, voc, None, pause_before_ms=10, pause_after_ms=20)
+    assert audio.dtype == np.int16 and audio.ndim == 1
+    s = ljspeech_audio_settings()
+    ref_mel = glow_tts_np.glow_tts_infer(gsd, HP.TINY_GLOW, ids, None, 0.0, 1.0)
+    ref = audio_np.audio_float_to_int16(hifi_gan_np.hifigan_infer(vsd, HP.TINY_HIFIGAN, audio_np.mel_to_vocoder_input(ref_mel, s)))
+    before, after = 220, 441
+    assert audio.shape[0] == before + ref.shape[0] + after
+    assert np.all(audio[:before] == 0) and np.all(audio[-after:] == 0)
+    assert np.abs(audio[before:-after].astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    # reference-style array in, int16 out (`mels_to_audio` with an already transformed ndarray)
+    a2 = voc.mels_to_audio(audio_np.mel_to_vocoder_input(ref_mel, s)[None])
+    assert np.abs(a2.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    # np.asarray on the returned mel gives the reference's [1, M, F] array
+    mel = tts.phonemes_to_mels(ids, {"noise_scale": 0.0})
+    assert np.asarray(mel).shape == (1, HP.TINY_GLOW.mel_channels, ref_mel.shape[1])
+    np.testing.assert_allclose(np.asarray(mel)[0], ref_mel, atol=2e-5)
+
+
+def test_phonemes_to_speech_keeps_submission_order(emu_library, voice_dirs):
+    gdir, vdir, gsd, vsd = voice_dirs
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, library_path=emu_library)
+    rng = np.random.default_rng(8)
+    sents = [(f"s{i}", synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols)) for i, n in enumerate((12, 6, 9))]
+    res = list(larynx_amd.phonemes_to_speech(sents, tts, voc, tts_settings={"noise_scale": 0.0}))
+    assert [r.text for r in res] == ["s0", "s1", "s2"] and all(r.sample_rate == 22050 for r in res)
+    for (text, ids), r in zip(sents, res):
+        one = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
+        assert np.array_equal(one, r.audio)
+
+
+def test_unsupported_requests_raise(emu_library, voice_dirs):
+    gdir, vdir, *_ = voice_dirs
+    with pytest.raises(ValueError):
+        larynx_amd.load_tts_model("tacotron2", gdir, library_path=emu_library)
+    with pytest.raises(ValueError):
+        larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, backend=InferenceBackend.ONNX, library_path=emu_library)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, library_path=emu_library)
+    with pytest.raises(NotImplementedError):
+        voc.mels_to_audio(np.zeros((1, HP.TINY_HIFIGAN.num_mels, 4), np.float32), {"denoiser_strength": 0.01})

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the round's measurement evidence on the GPU box (run through gpurun):
+#   kernel trace + stats of the bench command, HBM PMC passes (FETCH_SIZE and
+#   WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes), MFMA-busy PMC pass.
+# Usage: tools/profile_round.sh r01
+set -u
+R=${1:-r01}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq -o sq --output-format csv -- $BENCH > $OUT/bench_sq.log 2>&1
+ls -R $OUT | head -40
+# keep the merged-back payload small: counter CSVs can be large
+for f in $OUT/*/*counter_collection.csv; do python tools/pmc_reduce.py $f > ${f%.csv}_by_kernel.csv; rm -f $f; done
+rm -f $OUT/*/*_agent_info.csv
+du -sh $OUT
