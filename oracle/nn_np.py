@@ -29,9 +29,12 @@ def conv1d(x: np.ndarray, w: np.ndarray, b=None, dilation: int = 1, padding: int
     xp = np.zeros((cin, L + 2 * padding), F32)
     xp[:, padding : padding + L] = x
     lout = L + 2 * padding - dilation * (k - 1)
+    wt = np.ascontiguousarray(w.transpose(2, 0, 1))  # [K][Cout][Cin]: contiguous GEMM operands
     y = np.zeros((cout, lout), F32)
+    tmp = np.empty((cout, lout), F32)
     for j in range(k):
-        y += w[:, :, j] @ xp[:, j * dilation : j * dilation + lout]
+        np.matmul(wt[j], xp[:, j * dilation : j * dilation + lout], out=tmp)
+        y += tmp
     if b is not None:
         y += b.reshape(-1, 1)
     return y
@@ -42,8 +45,9 @@ def conv_transpose1d(x: np.ndarray, w: np.ndarray, b, stride: int, padding: int)
     cin, cout, k = w.shape
     L = x.shape[1]
     full = np.zeros((cout, (L - 1) * stride + k), F32)
+    wt = np.ascontiguousarray(w.transpose(2, 1, 0))  # [K][Cout][Cin]
     for j in range(k):
-        full[:, j : j + (L - 1) * stride + 1 : stride] += w[:, :, j].T @ x
+        full[:, j : j + (L - 1) * stride + 1 : stride] += wt[j] @ x
     y = full[:, padding : full.shape[1] - padding]
     if b is not None:
         y = y + b.reshape(-1, 1)

@@ -58,3 +58,17 @@ def test_duration_expansion_edge_cases():
     assert list(idx) == [0, 1, 1, 1, 2, 3, 3, 3]
     _, F, idx = glow_tts_np.durations_to_frames(np.log(np.array([1.0, 2.0], np.float32)), 1.0, 2)
     assert F == 2 and list(idx) == [0, 1]  # 3 frames -> truncated to 2
+
+
+def test_torch_operator_port_matches_numpy_oracle():
+    """bench.py times this variant as the CPU baseline; it must be the same function."""
+    pytest.importorskip("torch")
+    from larynx_amd import hparams as HP
+    from oracle import hifi_gan_torch
+
+    for hp in (HP.HIFIGAN_MEDIUM, HP.HIFIGAN_LOW):
+        vsd = synthetic.make_hifigan_state_dict(hp, seed=1234)
+        mel = (np.random.default_rng(0).standard_normal((80, 40)) * 3).astype(np.float32)
+        a = hifi_gan_torch.hifigan_infer_torch(vsd, hp, mel)
+        b = hifi_gan_np.hifigan_infer(vsd, hp, mel)
+        assert np.sqrt(np.mean((a - b) ** 2)) < 2e-6

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/<round>/ (tools/profile_round.sh) into the committed evidence
+under profiles/: kernel stats, PMC-derived HBM traffic and MFMA utilisation."""
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = Path("gpurun_out") / R
+DST = Path("profiles")
+DST.mkdir(exist_ok=True)
+
+
+def load(path):
+    d = {}
+    for r in csv.DictReader(open(path)):
+        d.setdefault(r["kernel"], {})[r["counter"]] = (int(r["dispatches"]), float(r["sum"]))
+    return d
+
+
+shutil.copy(SRC / "trace" / "trace_kernel_stats.csv", DST / f"{R}_kernel_stats.csv")
+for name in ("fetch", "write", "sq"):
+    shutil.copy(SRC / f"pmc_{name}" / f"{name}_counter_collection_by_kernel.csv", DST / f"{R}_pmc_{name}_by_kernel.csv")
+fetch, write, sq = (load(DST / f"{R}_pmc_{n}_by_kernel.csv") for n in ("fetch", "write", "sq"))
+stats = {r["Name"]: r for r in csv.DictReader(open(DST / f"{R}_kernel_stats.csv"))}
+
+
+def short(n):
+    import re
+
+    m = re.search(r"conv_mfma_kernel<([^>]*)>", n)
+    return f"conv_mfma_kernel<{m.group(1)}>" if m else re.sub(r"\(.*", "", n).replace("void ", "").replace("mi355tts::", "")
+
+
+rows = []
+for full, st in stats.items():
+    k = short(full)
+    calls = int(st["Calls"])
+    avg_us = float(st["AverageNs"]) / 1e3
+    f = fetch.get(k, {}).get("FETCH_SIZE")
+    w = write.get(k, {}).get("WRITE_SIZE")
+    s = sq.get(k, {})
+    util = None
+    clk = None
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in s and "GRBM_GUI_ACTIVE" in s and s["GRBM_GUI_ACTIVE"][1] > 0:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
+        util = s["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (s["GRBM_GUI_ACTIVE"][1] / 8.0 * 1024.0)
+    rows.append(dict(kernel=k, calls=calls, avg_us=avg_us, pct=float(st["Percentage"]),
+                     fetch_kb=(f[1] / f[0]) if f else None, write_kb=(w[1] / w[0]) if w else None, mfma_util=util))
+rows.sort(key=lambda r: -r["pct"])
+with open(DST / f"{R}_summary.md", "w") as out:
+    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches`\n\n")
+    out.write("Sources: `--kernel-trace --stats` (durations), separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and SQ passes "
+              "(tools/profile_round.sh).  FETCH/WRITE are KB per dispatch as rocprofv3 reports them; on gfx950 FETCH_SIZE "
+              "under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md §HBM) — the conv kernel reads its "
+              "activations 4 B/lane and its weights 16 B/lane, so the read figure is a lower bound.  MFMA util = "
+              "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n\n")
+    out.write("| kernel | calls | avg us | % time | FETCH KB | WRITE KB | MFMA util |\n|---|---:|---:|---:|---:|---:|---:|\n")
+    for r in rows:
+        fk = f"{r['fetch_kb']:.0f}" if r["fetch_kb"] is not None else "-"
+        wk = f"{r['write_kb']:.0f}" if r["write_kb"] is not None else "-"
+        mu = f"{100*r['mfma_util']:.1f}%" if r["mfma_util"] is not None else "-"
+        out.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.2f} | {fk} | {wk} | {mu} |\n")
+# dominant kernel class = the LINEAR conv instances with K in {3,7,11} (HiFi-GAN ResBlocks)
+dom = [r for r in rows if r["kernel"].startswith("conv_mfma_kernel<") and r["kernel"].split("<")[1].split(",")[0] in ("3", "7", "11") and r["kernel"].rstrip(">").endswith(" 0")]
+n = sum(r["calls"] for r in dom)
+traffic = sum(r["calls"] * ((r["fetch_kb"] or 0) + (r["write_kb"] or 0)) for r in dom) * 1024.0 / n
+avg_us = sum(r["calls"] * r["avg_us"] for r in dom) / n
+json.dump({"round": R, "kernel_class": "conv_mfma_kernel LINEAR K in {3,7,11}", "dispatches": n, "avg_us": avg_us,
+           "hbm_bytes_per_launch_raw": traffic,
+           "note": "FETCH_SIZE+WRITE_SIZE (KB x 1024) per dispatch, separate PMC passes, no gfx950 x2 read correction applied"},
+          open(DST / f"{R}_roofline_traffic.json", "w"), indent=1)
+print(open(DST / f"{R}_summary.md").read())
+print(open(DST / f"{R}_roofline_traffic.json").read())
