@@ -50,7 +50,7 @@ struct ConvArgs {
   // packed weights (see pack_conv_weights in weights_pack.h) and packed bias
   const float* w;
   const float* bias;
-  int noct;  // ceil(Cin / 8)
+  int noct;  // octets per m-tile in the packed weights (ceil(Cin/8) rounded up to a multiple of 8)
   int Cin;
   int rows;  // number of valid virtual output rows
   int dil;
@@ -77,6 +77,10 @@ struct ConvArgs {
   int up;
   int up_pad;
   int half;
+  // micro-benchmark ablations (tools/conv_probe.py; results are WRONG when set):
+  // bit0 = no activation staging after chunk 0, bit1 = no A-fragment loads after
+  // the prologue, bit2 = no per-chunk barrier
+  int ablate;
 };
 
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const float* xb = a.x + (long long)b * a.x_bs;
   const float* xb2 = a.x2 ? a.x2 + (long long)b * a.x_bs : nullptr;
   const float* xb3 = a.x3 ? a.x3 + (long long)b * a.x_bs : nullptr;
-  const int nchunks = a.noct / OCTS;  // noct is padded to a multiple of OCTS at pack time
+  // whole chunks covering the real channels; the packed weights are zero-padded past Cin
+  const int nchunks = ((a.Cin + 7) / 8 + OCTS - 1) / OCTS;
 
   // ---- staging of the activation tile (global -> VGPR -> LDS), branch-free:
   // every lane loads from a clamped in-range address and zeroes by select, so the
@@ -136,28 +141,42 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int cin_last = a.Cin - 1;
   const int lin_last = Lin - 1;
   auto gload = [&](int chunk, float (&pre)[NR * NC]) {
+    int off[NR * NC];
+    bool ok[NR * NC];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int ci = chunk * CI_C + ty + NWAVES * i;
       const bool row_ok = ci < a.Cin;
-      const long long roff = (long long)(row_ok ? ci : cin_last) * a.x_ld;
-      const float* xr = xb + roff;
+      const int roff = (row_ok ? ci : cin_last) * a.x_ld;  // C*L of one batch row fits in 31 bits
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const int cc = tx + 64 * j;
         const int ti = t0 - a.pad + cc;
-        const bool ok = row_ok && cc < roww && ti >= 0 && ti < Lin;
-        const int tc = ti < 0 ? 0 : (ti > lin_last ? lin_last : ti);
-        float v = xr[tc];
-        if (xb2) {  // wave-uniform
-          v += xb2[roff + tc];
-          if (xb3) v += xb3[roff + tc];
-          v = v / a.in_div;
-        }
-        v = ok ? v : 0.f;
-        v = v > 0.f ? v : v * slope;
-        pre[i * NC + j] = v;
+        ok[i * NC + j] = row_ok && cc < roww && ti >= 0 && ti < Lin;
+        off[i * NC + j] = roff + (ti < 0 ? 0 : (ti > lin_last ? lin_last : ti));
       }
+    }
+#pragma unroll
+    for (int e = 0; e < NR * NC; ++e) pre[e] = xb[off[e]];
+    if (xb2) {  // wave-uniform: MRF average of the previous stage's chains, batched
+      float t2[NR * NC];
+#pragma unroll
+      for (int e = 0; e < NR * NC; ++e) t2[e] = xb2[off[e]];
+#pragma unroll
+      for (int e = 0; e < NR * NC; ++e) pre[e] += t2[e];
+      if (xb3) {
+#pragma unroll
+        for (int e = 0; e < NR * NC; ++e) t2[e] = xb3[off[e]];
+#pragma unroll
+        for (int e = 0; e < NR * NC; ++e) pre[e] += t2[e];
+      }
+#pragma unroll
+      for (int e = 0; e < NR * NC; ++e) pre[e] = pre[e] / a.in_div;
+    }
+#pragma unroll
+    for (int e = 0; e < NR * NC; ++e) {
+      float v = ok[e] ? pre[e] : 0.f;
+      pre[e] = v > 0.f ? v : v * slope;
     }
   };
   auto lstore = [&](int buf, const float (&pre)[NR * NC]) {
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   auto do_chunk = [&](int chunk, float (&pre_load)[NR * NC], const float (&pre_store)[NR * NC]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
-    if (chunk + 2 < nchunks) gload(chunk + 2, pre_load);
+    if (chunk + 2 < nchunks && !(a.ablate & 1)) gload(chunk + 2, pre_load);
     const float* xt = xs + buf * (CI_C * XW) + b_off + kg * 8 * XW;
     float bcur[4][NB], bnxt[4][NB];
 #pragma unroll
@@ -232,7 +251,8 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     for (int s = 0; s < S; ++s) {
       // issue the loads for later steps first, then this step's MFMAs
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) ar[(s + 2) % 3][mb] = wq[mb][a_index(chunk, s + 2)];
+      for (int mb = 0; mb < MB; ++mb)
+        if (!(a.ablate & 2)) ar[(s + 2) % 3][mb] = wq[mb][a_index(chunk, s + 2)];
       if (s + 1 < S) {
         const int oi = (s + 1) / K;
         const int k = (s + 1) - oi * K;
@@ -275,8 +295,8 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
         ar[1][mb] = r1[mb];
       }
     }
-    if (more) lstore(buf ^ 1, pre_store);
-    __syncthreads();
+    if (more && !(a.ablate & 1)) lstore(buf ^ 1, pre_store);
+    if (!(a.ablate & 4)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunks; chunk += 2) {
     do_chunk(chunk, preA, preB);

@@ -86,7 +86,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
     p = pack_conv(
         Cout, d.MB, Cin, K, [&](int v) { return v; },
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
-        d.has_bias, K == 1 ? 8 : 4);
+        d.has_bias, 8);
   } else if (layout == ROWS_PAIR) {
     // virtual tiles (2p, 2p+1) = rows [32p, 32p+32) of the first and second half
     const int half = half_or_up;
@@ -101,7 +101,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
           return (tile & 1) * half + c;
         },
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
-        d.has_bias, K == 1 ? 8 : 4);
+        d.has_bias, 8);
   } else {
     // ConvTranspose1d(Cin, Cout, Ku, stride u, padding (Ku-u)/2) as a Kt = Ku/u tap
     // conv over q with virtual rows v = co*u + r:
@@ -118,7 +118,7 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
           const int m = Kt - 1 - k;
           return w[((size_t)ci * Cout + co) * Ku + m * u + r];
         },
-        [&](int v) { return bias[v / u]; }, d.has_bias, Kt == 1 ? 8 : 4);
+        [&](int v) { return bias[v / u]; }, d.has_bias, 8);
   }
   d.mtiles = p.mtiles;
   d.noct = p.noct;
@@ -472,10 +472,11 @@ template <> struct ConvCfg<7> { static constexpr int HALO = 72; };
 template <> struct ConvCfg<11> { static constexpr int HALO = 52; };
 
 // Tile shapes (all 512 threads):
-//   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (GlowTTS, stage 0 at batch 1)
+//   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
+//   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
 //   NB1   : 4 time-waves x 2 k-groups, 128 columns
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2 };
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -485,13 +486,15 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   constexpr int CI_SMALL = (K == 1) ? 64 : 32;
   if ((K - 1) * a.dil > HALO) return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
   if (MB == 2) {
-    if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
-    if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
@@ -513,12 +516,13 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   a.rows = c.rows;
   const int MB = c.MB;
   const int ytiles = c.mtiles / MB;
-  // tile shape by how many workgroups the launch yields (256 CUs)
-  const long long t128 = (long long)((n_max + 127) / 128) * ytiles * B;
-  const long long t256 = (long long)((n_max + 255) / 256) * ytiles * B;
-  int shape = TILE_NB1;
-  if (t256 >= 768) shape = TILE_NB2;
-  else if (t128 < 384) shape = TILE_SMALL;
+  // Tile shape: the largest tile that still yields >= 1024 workgroups (4 per CU: the
+  // measured sweet spot of tools/conv_sweep.py), otherwise the smallest tile.
+  auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
+  int shape = TILE_TINY;
+  if (tiles(256) >= 1024) shape = TILE_NB2;
+  else if (tiles(128) >= 1024) shape = TILE_NB1;
+  else if (tiles(64) >= 1024) shape = TILE_SMALL;
   {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
     static const int forced = [] {
       const char* e = std::getenv("MI355TTS_FORCE_TILE");
@@ -527,9 +531,9 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     int f = forced;
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
     if (g_pin_tile >= 0) f = g_pin_tile;
-    if (f >= TILE_SMALL && f <= TILE_NB2) shape = f;
+    if (f >= TILE_SMALL && f <= TILE_TINY) shape = f;
   }
-  const int T_T = shape == TILE_SMALL ? 64 : (shape == TILE_NB1 ? 128 : 256);
+  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB1 ? 128 : 256);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   hipStream_t s = stream ? stream : w->stream;
@@ -1723,6 +1727,7 @@ extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout
   a.in_const = L;
   a.out_const = L;
   a.in_slope = 0.1f;
+  if (const char* ab = std::getenv("MI355TTS_BENCH_ABLATE")) a.ablate = std::atoi(ab);
   const bool prof = ctx->profiling;
   ctx->profiling = false;
   g_pin_tile = tile_shape;
