@@ -95,8 +95,6 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   constexpr int NT = 64 * NWAVES;
   constexpr int T_T = WN * NB * 32;  // time columns per workgroup
   constexpr int XW = T_T + HALO;     // LDS row stride (floats)
-  constexpr int NR = CI_C / NWAVES;  // staging rows per thread
-  constexpr int NC = (XW + 63) / 64;
   constexpr int OCTS = CI_C / 8;     // octets per staged chunk
   constexpr int NO = OCTS / KS;      // octets per chunk per k-group
   constexpr int S = NO * K;          // MFMA k-steps per chunk per k-group
@@ -112,8 +110,6 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int wave = tid >> 6;
   const int wn = wave % WN;
   const int kg = wave / WN;
-  const int tx = lane;
-  const int ty = wave;
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * T_T;
   const int mt0 = blockIdx.y * MB;
@@ -132,62 +128,88 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   // whole chunks covering the real channels; the packed weights are zero-padded past Cin
   const int nchunks = ((a.Cin + 7) / 8 + OCTS - 1) / OCTS;
 
-  // ---- staging of the activation tile (global -> VGPR -> LDS), branch-free:
-  // every lane loads from a clamped in-range address and zeroes by select, so the
-  // loads issue back to back instead of one exec-masked branch each.
+  // ---- staging of the activation tile (global -> VGPR -> LDS), 16 bytes per lane:
+  // the tile starts at the 4-aligned column t0 - PA (PA = pad rounded up to 4), every
+  // lane loads whole float4s from clamped in-range addresses and zeroes the
+  // out-of-range elements by select (no branches, loads issue back to back), and
+  // lands them with ds_write_b128.  Row strides (x_ld) are multiples of 4 floats.
   // Two register sets: the tile for chunk c+2 is requested while chunk c computes,
   // so a staged chunk has two MFMA phases (not one) to cover the L2/MALL latency.
-  float preA[NR * NC], preB[NR * NC];
+  constexpr int XW4 = XW / 4;
+  constexpr int NF4 = CI_C * XW4;             // float4s per staged chunk
+  constexpr int NE = (NF4 + NT - 1) / NT;     // per thread, flattened over (row, float4) so no lane idles
+  static_assert(XW % 4 == 0, "LDS row stride must be a multiple of 4 floats");
+  float4 preA[NE], preB[NE];
+  const int PA = (a.pad + 3) & ~3;
+  const int used4 = (PA - a.pad + roww + 3) >> 2;  // float4s per row actually needed
   const int cin_last = a.Cin - 1;
-  const int lin_last = Lin - 1;
-  auto gload = [&](int chunk, float (&pre)[NR * NC]) {
-    int off[NR * NC];
-    bool ok[NR * NC];
+  const int ld_last4 = a.x_ld - 4;
+  auto gload = [&](int chunk, float4 (&pre)[NE]) {
+    int off[NE];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int ci = chunk * CI_C + ty + NWAVES * i;
-      const bool row_ok = ci < a.Cin;
-      const int roff = (row_ok ? ci : cin_last) * a.x_ld;  // C*L of one batch row fits in 31 bits
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const int cc = tx + 64 * j;
-        const int ti = t0 - a.pad + cc;
-        ok[i * NC + j] = row_ok && cc < roww && ti >= 0 && ti < Lin;
-        off[i * NC + j] = roff + (ti < 0 ? 0 : (ti > lin_last ? lin_last : ti));
-      }
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / XW4, f = e - row * XW4;
+      const int ci = chunk * CI_C + (row < CI_C ? row : CI_C - 1);
+      const int c0 = t0 - PA + 4 * f;
+      off[i] = (ci < a.Cin ? ci : cin_last) * a.x_ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0));
     }
 #pragma unroll
-    for (int e = 0; e < NR * NC; ++e) pre[e] = xb[off[e]];
+    for (int i = 0; i < NE; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + off[i]);
     if (xb2) {  // wave-uniform: MRF average of the previous stage's chains, batched
-      float t2[NR * NC];
+      float4 t2[NE];
 #pragma unroll
-      for (int e = 0; e < NR * NC; ++e) t2[e] = xb2[off[e]];
+      for (int i = 0; i < NE; ++i) t2[i] = *reinterpret_cast<const float4*>(xb2 + off[i]);
 #pragma unroll
-      for (int e = 0; e < NR * NC; ++e) pre[e] += t2[e];
+      for (int i = 0; i < NE; ++i) {
+        pre[i].x += t2[i].x;
+        pre[i].y += t2[i].y;
+        pre[i].z += t2[i].z;
+        pre[i].w += t2[i].w;
+      }
       if (xb3) {
 #pragma unroll
-        for (int e = 0; e < NR * NC; ++e) t2[e] = xb3[off[e]];
+        for (int i = 0; i < NE; ++i) t2[i] = *reinterpret_cast<const float4*>(xb3 + off[i]);
 #pragma unroll
-        for (int e = 0; e < NR * NC; ++e) pre[e] += t2[e];
+        for (int i = 0; i < NE; ++i) {
+          pre[i].x += t2[i].x;
+          pre[i].y += t2[i].y;
+          pre[i].z += t2[i].z;
+          pre[i].w += t2[i].w;
+        }
       }
 #pragma unroll
-      for (int e = 0; e < NR * NC; ++e) pre[e] = pre[e] / a.in_div;
+      for (int i = 0; i < NE; ++i) {
+        pre[i].x = pre[i].x / a.in_div;
+        pre[i].y = pre[i].y / a.in_div;
+        pre[i].z = pre[i].z / a.in_div;
+        pre[i].w = pre[i].w / a.in_div;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < NR * NC; ++e) {
-      float v = ok[e] ? pre[e] : 0.f;
-      pre[e] = v > 0.f ? v : v * slope;
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / XW4, f = e - row * XW4;
+      const int c0 = t0 - PA + 4 * f;
+      const bool fok = chunk * CI_C + row < a.Cin && f < used4;
+      float4 v = pre[i];
+      v.x = (fok && c0 >= 0 && c0 < Lin) ? v.x : 0.f;
+      v.y = (fok && c0 + 1 >= 0 && c0 + 1 < Lin) ? v.y : 0.f;
+      v.z = (fok && c0 + 2 >= 0 && c0 + 2 < Lin) ? v.z : 0.f;
+      v.w = (fok && c0 + 3 >= 0 && c0 + 3 < Lin) ? v.w : 0.f;
+      v.x = v.x > 0.f ? v.x : v.x * slope;
+      v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope;
+      v.w = v.w > 0.f ? v.w : v.w * slope;
+      pre[i] = v;
     }
   };
-  auto lstore = [&](int buf, const float (&pre)[NR * NC]) {
-    float* dst = xs + buf * (CI_C * XW);
+  auto lstore = [&](int buf, const float4 (&pre)[NE]) {
+    float4* dst = reinterpret_cast<float4*>(xs + buf * (CI_C * XW));
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const int cc = tx + 64 * j;
-        if (cc < XW) dst[(ty + NWAVES * i) * XW + cc] = pre[i * NC + j];
-      }
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      if (e < NF4) dst[e] = pre[i];  // rows are XW = 4*XW4 floats: the flat float4 index IS the LDS index
     }
   };
 
@@ -235,9 +257,9 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     ar[1][mb] = wq[mb][a_index(0, 1)];
   }
 
-  const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31);
+  const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31) + (PA - a.pad);
 
-  auto do_chunk = [&](int chunk, float (&pre_load)[NR * NC], const float (&pre_store)[NR * NC]) {
+  auto do_chunk = [&](int chunk, float4 (&pre_load)[NE], const float4 (&pre_store)[NE]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
     if (chunk + 2 < nchunks && !(a.ablate & 1)) gload(chunk + 2, pre_load);

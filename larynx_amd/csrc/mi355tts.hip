@@ -466,17 +466,18 @@ static void launch_conv_inst(hipStream_t s, dim3 grid, const ConvArgs& a) {
 template <int K> struct ConvCfg;
 template <> struct ConvCfg<1> { static constexpr int HALO = 0; };
 template <> struct ConvCfg<2> { static constexpr int HALO = 4; };
-template <> struct ConvCfg<3> { static constexpr int HALO = 12; };
-template <> struct ConvCfg<5> { static constexpr int HALO = 24; };
-template <> struct ConvCfg<7> { static constexpr int HALO = 72; };
-template <> struct ConvCfg<11> { static constexpr int HALO = 52; };
+template <> struct ConvCfg<3> { static constexpr int HALO = 16; };
+template <> struct ConvCfg<5> { static constexpr int HALO = 28; };
+template <> struct ConvCfg<7> { static constexpr int HALO = 76; };
+template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 
 // Tile shapes (all 512 threads):
+//   FLAT  : 4 time-waves x 1 k-group (256 threads), 128 columns — short reductions (C_in*K <= 512): no k-split, no LDS sum
 //   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
 //   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
 //   NB1   : 4 time-waves x 2 k-groups, 128 columns
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3 };
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_FLAT = 4 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -484,16 +485,21 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   constexpr int HALO = ConvCfg<K>::HALO;
   constexpr int CI_BIG = (K == 1) ? 64 : (K <= 5) ? 32 : 16;
   constexpr int CI_SMALL = (K == 1) ? 64 : 32;
-  if ((K - 1) * a.dil > HALO) return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
+  // the staged tile starts at the 4-aligned column t0 - roundup(pad, 4)
+  if ((K - 1) * a.dil + ((4 - a.pad % 4) % 4) > HALO)
+    return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
+  if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
   if (MB == 2) {
-    if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
+    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 2, 1, 4, 1, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
-    if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
+    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 1, 1, 4, 1, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
@@ -531,9 +537,9 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     int f = forced;
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
     if (g_pin_tile >= 0) f = g_pin_tile;
-    if (f >= TILE_SMALL && f <= TILE_TINY) shape = f;
+    if (f >= TILE_SMALL && f <= TILE_FLAT) shape = f;
   }
-  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB1 ? 128 : 256);
+  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   hipStream_t s = stream ? stream : w->stream;
@@ -1061,7 +1067,8 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
     mx = std::max(mx, frames[b]);
   }
   mi355tts_mel* m = nullptr;
-  CHECK(mel_alloc(ctx, B, M, ld, &m));
+  const int ldp = (ld + 3) & ~3;
+  CHECK(mel_alloc(ctx, B, M, ldp, &m));
   m->max_frames = mx;
   for (int b = 0; b < B; ++b) m->frames[b] = frames[b];
   Worker* w = nullptr;
@@ -1071,10 +1078,12 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
     return rc;
   }
   WorkerGuard guard{ctx, w};
-  const size_t n = (size_t)B * M * ld;
+  const size_t n = (size_t)B * M * ldp;
   hipError_t e = hipMemcpyAsync(m->frames_dev, frames, sizeof(int) * B, hipMemcpyHostToDevice, w->stream);
+  if (e == hipSuccess && n) e = hipMemsetAsync(m->raw, 0, n * sizeof(float), w->stream);
   if (e == hipSuccess && n)
-    e = hipMemcpyAsync(m->raw, mel, n * sizeof(float), (flags & MI355TTS_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, w->stream);
+    e = hipMemcpy2DAsync(m->raw, sizeof(float) * ldp, mel, sizeof(float) * ld, sizeof(float) * ld, (size_t)B * M,
+                         (flags & MI355TTS_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, w->stream);
   if (e == hipSuccess && n) {
     if (audio) {
       hipLaunchKernelGGL(mel_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w->stream, m->raw, m->voc,
@@ -1193,8 +1202,12 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
-      hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
-                         h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
+      if (Pmax <= ATTM_MAXP)
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3((Pmax + 31) / 32, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
+                           h.window_size, A + L.ek, A + L.ev, t2, bsH, P);
+      else
+        hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
+                           h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
     }
     {
       ConvArgs a = base_args(t2, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, 0);
@@ -1427,7 +1440,8 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   hipStream_t s = w->stream;
   const int C0 = h.upsample_initial_channel;
   // largest [C][L] plane over conv_pre and the stages
-  size_t plane = (size_t)C0 * F;
+  const int Fp = (F + 3) & ~3;  // row strides are multiples of 4 floats (16-byte staging loads)
+  size_t plane = (size_t)C0 * Fp;
   {
     long long L = F;
     for (int i = 0; i < h.num_upsamples; ++i) {
@@ -1470,7 +1484,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   int ncur = 1;
   float* xu = buf[1];
   {  // conv_pre (models.py:187)
-    ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * F, F, d_frames, 1, 1, 3);
+    ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * Fp, Fp, d_frames, 1, 1, 3);
     CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO));
   }
   auto set_inputs = [&](ConvArgs& a) {
@@ -1482,6 +1496,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   };
   int mul = 1;
   int Lin = F;
+  int ldin = Fp;
   int ch = C0;
   int flip = 0;  // which half of the chain-output buffers this stage writes
   for (int i = 0; i < h.num_upsamples; ++i) {
@@ -1489,7 +1504,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     const int cout = C0 >> (i + 1);
     const int Lout = Lin * u;
     {  // x = ups[i](leaky_relu(x, 0.1))  (models.py:189-190)
-      ConvArgs a = base_args(cur[0], (long long)ch * Lin, Lin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
+      ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
       set_inputs(a);
       a.in_slope = 0.1f;
       a.up = u;
@@ -1568,9 +1583,10 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
       ncur = 1;
     }
     Lin = Lout;
+    ldin = Lout;
   }
   {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
-    ConvArgs a = base_args(cur[0], (long long)ch * Lin, Lin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
+    ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
     set_inputs(a);
     a.in_slope = 0.01f;
     a.out_act = ACT_TANH;
@@ -1636,7 +1652,8 @@ static int op_conv_common(mi355tts_ctx* ctx, const float* x, int B, int Cin, int
   WorkerGuard guard{ctx, w};
   Carver cv;
   const size_t o_w = cv.take(ab.host.size() * sizeof(float));
-  const size_t o_x = cv.take(sizeof(float) * (size_t)B * Cin * L);
+  const int Lp = (L + 3) & ~3;
+  const size_t o_x = cv.take(sizeof(float) * (size_t)B * Cin * Lp);
   const size_t o_y = cv.take(sizeof(float) * (size_t)B * Cout * Lout);
   const size_t o_l = cv.take(sizeof(int) * B);
   CHECK(reserve(w, cv.pos));
@@ -1647,7 +1664,8 @@ static int op_conv_common(mi355tts_ctx* ctx, const float* x, int B, int Cin, int
   int* dl = (int*)(base + o_l);
   hipStream_t s = w->stream;
   HIPCHECK(hipMemcpyAsync(dw, ab.host.data(), ab.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCHECK(hipMemcpyAsync(dx, x, sizeof(float) * (size_t)B * Cin * L, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * Cin * Lp, s));
+  HIPCHECK(hipMemcpy2DAsync(dx, sizeof(float) * Lp, x, sizeof(float) * L, sizeof(float) * L, (size_t)B * Cin, hipMemcpyHostToDevice, s));
   HIPCHECK(hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * Cout * Lout, s));
   std::vector<int> hl(B, L);
   if (lens)
@@ -1660,14 +1678,14 @@ static int op_conv_common(mi355tts_ctx* ctx, const float* x, int B, int Cin, int
   int rc;
   if (transposed) {
     const int u = dil_or_stride;
-    ConvArgs a = base_args(dx, (long long)Cin * L, L, dl, 1, dy, (long long)Cout * Lout, Lout, dl, u, 1, K / u - 1);
+    ConvArgs a = base_args(dx, (long long)Cin * Lp, Lp, dl, 1, dy, (long long)Cout * Lout, Lout, dl, u, 1, K / u - 1);
     a.in_slope = in_slope;
     a.up = u;
     a.up_pad = (K - u) / 2;
     rc = launch_conv(ctx, w, c, a, EPI_UPSAMPLE, B, L + K / u - 1, KC_UPSAMPLE);
   } else {
     const int dil = dil_or_stride;
-    ConvArgs a = base_args(dx, (long long)Cin * L, L, dl, 1, dy, (long long)Cout * Lout, Lout, dl, 1, dil, (K * dil - dil) / 2);
+    ConvArgs a = base_args(dx, (long long)Cin * Lp, Lp, dl, 1, dy, (long long)Cout * Lout, Lout, dl, 1, dil, (K * dil - dil) / 2);
     a.in_slope = in_slope;
     a.out_act = out_act;
     rc = launch_conv(ctx, w, c, a, EPI_LINEAR, B, L, KC_RESBLOCK);
@@ -1691,8 +1709,8 @@ extern "C" int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, i
 
 extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, int dilation, int L,
                                      int tile_shape, int iters, float* ms_per_launch) {
-  if (!ctx || !ms_per_launch || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0 || iters <= 0 || !(K % 2))
-    return fail(MI355TTS_ERR_INVALID, "bad argument");
+  if (!ctx || !ms_per_launch || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0 || iters <= 0 || !(K % 2) || (L % 4))
+    return fail(MI355TTS_ERR_INVALID, "bad argument (L must be a multiple of 4)");
   HIPCHECK(hipSetDevice(ctx->device));
   std::vector<float> wh((size_t)Cout * Cin * K), bh(Cout), xh((size_t)B * Cin * L);
   uint32_t st = 12345u;

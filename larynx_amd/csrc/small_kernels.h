@@ -255,6 +255,124 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long l
   if (lane + 64 < dk) ob[(long long)(lane + 64) * out_ld] = acc1;
 }
 
+// G4 on the matrix cores (the path used for P <= ATTM_MAXP): one workgroup per
+// (32 query rows, head).  S = Q K^T and O^T = V P^T are v_mfma_f32_32x32x2_f32
+// GEMMs whose operands come straight out of the [channel][time] qkv layout
+// (lanes run along time = coalesced); the score block lives in LDS between the
+// two, where the 9-wide relative-position band is added and the rows are
+// soft-maxed with wave64 reductions.
+constexpr int ATTM_MAXP = 768;
+constexpr int ATTM_PS = ATTM_MAXP + 1;  // odd row stride: conflict-free column reads
+typedef float att_floatx16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
+                                                             int nheads, int window, const float* ek, const float* ev,
+                                                             float* out, long long out_bs, int out_ld) {
+  __shared__ float S[32 * ATTM_PS];
+  __shared__ float vs[ATT_MAXDK * 65];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = len[b];
+  const int i0 = blockIdx.x * 32;
+  if (i0 >= P) return;
+  const int dk = H / nheads;
+  const int nrel = 2 * window + 1;
+  const float scale = rsqrtf((float)dk);
+  const float* q = qkv + (long long)b * bs + (long long)(h * dk) * ld;
+  const float* k = q + (long long)H * ld;
+  const float* v = k + (long long)H * ld;
+  const int nkb = (P + 31) / 32;  // key blocks
+  const int col = lane & 31, half = lane >> 5;
+  const int rbase = 4 * half;
+  const int iq = min(i0 + col, P - 1);  // this lane's query column for A operands (clamped)
+
+  // ---- phase 1: S[i][j] = scale * q_i . k_j  (M = queries, N = keys, K-dim = channels)
+  for (int nb = wave; nb < nkb; nb += 4) {
+    const int jk = min(nb * 32 + col, P - 1);
+    att_floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < dk; c += 2) {
+      const float av = q[(long long)(c + half) * ld + iq];
+      const float bv = k[(long long)(c + half) * ld + jk];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    const int j = nb * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + rbase;
+      S[i * ATTM_PS + j] = (j < P) ? acc[r] * scale : -3.0e38f;
+    }
+  }
+  __syncthreads();
+  // ---- relative-key band: S[i][i+r-w] += scale * q_i . Ek[r]   (attentions.py:228-234)
+  for (int r = threadIdx.x >> 5; r < nrel; r += 8) {
+    const int i = threadIdx.x & 31;
+    const int gi = i0 + i;
+    const int j = gi + r - window;
+    if (gi < P && j >= 0 && j < P) {
+      float d = 0.f;
+      for (int c = 0; c < dk; ++c) d += q[(long long)c * ld + gi] * ek[r * dk + c];
+      S[i * ATTM_PS + j] += d * scale;
+    }
+  }
+  __syncthreads();
+  // ---- softmax over keys, one wave per row
+  for (int i = wave; i < 32; i += 4) {
+    float* row = S + i * ATTM_PS;
+    float mx = -3.0e38f;
+    for (int j = lane; j < P; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int j = lane; j < P; j += 64) {
+      const float e = expf(row[j] - mx);
+      row[j] = e;
+      den += e;
+    }
+    den = wave_sum(den);
+    const float inv = 1.0f / den;
+    for (int j = lane; j < nkb * 32; j += 64) row[j] = (j < P) ? row[j] * inv : 0.f;
+  }
+  __syncthreads();
+  // ---- phase 2: O^T[c][i] = sum_j v[c][j] p[i][j]   (M = channels, N = queries, K-dim = keys)
+  const int ncb = (dk + 31) / 32;
+  att_floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j0 = 0; j0 < nkb * 32; j0 += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < dk * 64; e += 256) {
+      const int c = e >> 6, jj = e & 63;
+      vs[c * 65 + jj] = (j0 + jj < P) ? v[(long long)c * ld + j0 + jj] : 0.f;
+    }
+    __syncthreads();
+    if (wave < ncb) {
+      const int c = min(wave * 32 + col, dk - 1);
+      const int jn = min(64, nkb * 32 - j0);
+      for (int jj = 0; jj < jn; jj += 2) {
+        const float av = (wave * 32 + col < dk) ? vs[c * 65 + jj + half] : 0.f;
+        const float bv = S[col * ATTM_PS + j0 + jj + half];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+    }
+  }
+  // (dk <= 128 = 4 channel blocks, one per wave)
+  if (wave >= ncb) return;
+  // ---- relative values on the band + store: out[c][i]      (attentions.py:246-253)
+  const int gi = i0 + col;  // this lane's query
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = wave * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+    if (c >= dk || gi >= P) continue;
+    float o = acc[r];
+    for (int rr = 0; rr < nrel; ++rr) {
+      const int j = gi + rr - window;
+      if (j >= 0 && j < P) o += S[col * ATTM_PS + j] * ev[rr * dk + c];
+    }
+    out[(long long)b * out_bs + (long long)(h * dk + c) * out_ld + gi] = o;
+  }
+}
+
 // G9a: durations.  w = exp(logw)*length_scale, w_ceil = ceil(w); cum = inclusive
 // cumsum; frames = max(sum,1) truncated to a multiple of n_sqz
 // (glow_tts/models.py:323-336).  One workgroup per batch row.

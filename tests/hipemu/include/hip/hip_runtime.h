@@ -220,6 +220,8 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
@@ -266,6 +268,7 @@ template <typename T> static inline hipError_t hipHostMalloc(T** p, size_t n, un
 hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t st = nullptr);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr);
 hipError_t hipStreamCreate(hipStream_t* s);
