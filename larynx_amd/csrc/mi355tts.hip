@@ -520,8 +520,8 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   a.noct = c.noct;
   a.Cin = c.Cin;
   a.rows = c.rows;
-  const int MB = c.MB;
-  const int ytiles = c.mtiles / MB;
+  int MB = c.MB;
+  int ytiles = c.mtiles / MB;
   // Tile shape: the largest tile that still yields >= 1024 workgroups (4 per CU: the
   // measured sweet spot of tools/conv_sweep.py), otherwise the smallest tile.
   auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
@@ -538,6 +538,12 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
     if (g_pin_tile >= 0) f = g_pin_tile;
     if (f >= TILE_SMALL && f <= TILE_FLAT) shape = f;
+  }
+  // a launch that cannot even give every CU one workgroup: halve the row tile too
+  // (32-row m-tiles are independent in the packed weights; paired epilogues need both)
+  if (shape == TILE_TINY && MB == 2 && (epi == EPI_LINEAR || epi == EPI_UPSAMPLE) && tiles(32) < 256) {
+    MB = 1;
+    ytiles = (c.rows + 31) / 32;
   }
   const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
@@ -1202,9 +1208,16 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
-      if (Pmax <= ATTM_MAXP)
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3((Pmax + 31) / 32, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
-                           h.window_size, A + L.ek, A + L.ev, t2, bsH, P);
+      const dim3 ag((Pmax + 31) / 32, nh, B);
+      const int dkh = H / nh;
+#define ATT_LAUNCH(NK)                                                                                                   \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK>), ag, dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,     \
+                     h.window_size, A + L.ek, A + L.ev, t2, bsH, P)
+      if (Pmax <= ATTM_MAXP && dkh <= 32) ATT_LAUNCH(16);
+      else if (Pmax <= ATTM_MAXP && dkh <= 64) ATT_LAUNCH(32);
+      else if (Pmax <= ATTM_MAXP && dkh <= 96) ATT_LAUNCH(48);
+      else if (Pmax <= ATTM_MAXP) ATT_LAUNCH(64);
+#undef ATT_LAUNCH
       else
         hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
                            h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);

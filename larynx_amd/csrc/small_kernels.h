@@ -265,11 +265,13 @@ constexpr int ATTM_MAXP = 768;
 constexpr int ATTM_PS = ATTM_MAXP + 1;  // odd row stride: conflict-free column reads
 typedef float att_floatx16 __attribute__((ext_vector_type(16)));
 
+template <int NK>  // MFMA k-steps covering the head dimension: 2*NK >= dk
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
                                                              int nheads, int window, const float* ek, const float* ev,
                                                              float* out, long long out_bs, int out_ld) {
   __shared__ float S[32 * ATTM_PS];
   __shared__ float vs[ATT_MAXDK * 65];
+  __shared__ float relS[32 * 33];
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int P = len[b];
@@ -286,35 +288,49 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
   const int rbase = 4 * half;
   const int iq = min(i0 + col, P - 1);  // this lane's query column for A operands (clamped)
 
-  // ---- phase 1: S[i][j] = scale * q_i . k_j  (M = queries, N = keys, K-dim = channels)
-  for (int nb = wave; nb < nkb; nb += 4) {
+  // ---- phase 1: S[i][j] = scale * q_i . k_j  (M = queries, N = keys, K-dim = channels).
+  // The query fragments are loaded once and stay in registers; every key block (and
+  // one extra block whose "keys" are the 2w+1 relative-position embeddings,
+  // attentions.py:228-234) costs one batch of loads + NK MFMAs.
+  float av[NK];
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    const int c = 2 * u + half;
+    const float t = q[(long long)(c < dk ? c : dk - 1) * ld + iq];
+    av[u] = c < dk ? t : 0.f;
+  }
+  for (int nb = wave; nb <= nkb; nb += 4) {
+    const bool band = nb == nkb;
     const int jk = min(nb * 32 + col, P - 1);
+    const int rr = col < nrel ? col : nrel - 1;
+    float bv[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      const int c = 2 * u + half;
+      const int cc = c < dk ? c : dk - 1;
+      const float t = band ? ek[rr * dk + cc] : k[(long long)cc * ld + jk];
+      bv[u] = (c < dk && (!band || col < nrel)) ? t : 0.f;
+    }
     att_floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int c = 0; c < dk; c += 2) {
-      const float av = q[(long long)(c + half) * ld + iq];
-      const float bv = k[(long long)(c + half) * ld + jk];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     const int j = nb * 32 + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + rbase;
-      S[i * ATTM_PS + j] = (j < P) ? acc[r] * scale : -3.0e38f;
+      if (band) relS[i * 33 + col] = acc[r] * scale;
+      else S[i * ATTM_PS + j] = (j < P) ? acc[r] * scale : -3.0e38f;
     }
   }
   __syncthreads();
-  // ---- relative-key band: S[i][i+r-w] += scale * q_i . Ek[r]   (attentions.py:228-234)
+  // ---- relative-key band: S[i][i+r-w] += scale * q_i . Ek[r]
   for (int r = threadIdx.x >> 5; r < nrel; r += 8) {
     const int i = threadIdx.x & 31;
     const int gi = i0 + i;
     const int j = gi + r - window;
-    if (gi < P && j >= 0 && j < P) {
-      float d = 0.f;
-      for (int c = 0; c < dk; ++c) d += q[(long long)c * ld + gi] * ek[r * dk + c];
-      S[i * ATTM_PS + j] += d * scale;
-    }
+    if (gi < P && j >= 0 && j < P) S[i * ATTM_PS + j] += relS[i * 33 + r];
   }
   __syncthreads();
   // ---- softmax over keys, one wave per row
@@ -341,9 +357,20 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int j0 = 0; j0 < nkb * 32; j0 += 64) {
     __syncthreads();
-    for (int e = threadIdx.x; e < dk * 64; e += 256) {
-      const int c = e >> 6, jj = e & 63;
-      vs[c * 65 + jj] = (j0 + jj < P) ? v[(long long)c * ld + j0 + jj] : 0.f;
+    for (int e0 = threadIdx.x; e0 < dk * 64; e0 += 8 * 256) {  // 8 loads in flight per thread
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256;
+        const int c = min(e >> 6, dk - 1), jj = e & 63;
+        t[u] = v[(long long)c * ld + min(j0 + jj, P - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256;
+        const int c = e >> 6, jj = e & 63;
+        if (c < dk) vs[c * 65 + jj] = (j0 + jj < P) ? t[u] : 0.f;
+      }
     }
     __syncthreads();
     if (wave < ncb) {
