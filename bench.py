@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--quality", default="high")
     ap.add_argument("--length-scale", type=float, default=0.65,
                     help="GlowTTS length_scale; 0.65 puts the synthetic 120-id utterances at SURVEY's standard ~624 frames")
+    ap.add_argument("--concurrency", type=int, default=3,
+                    help="utterances in flight per GPU in the timed region (host threads, each batch-1 call on its own "
+                         "HIP streams — the reference's ThreadPoolExecutor pattern); the single-stream latency is "
+                         "measured and reported next to it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-branches", action="store_true",
                     help="also run the headline pass with the MRF chains on one stream (for rocprofv3 kernel traces)")
@@ -156,17 +160,44 @@ def main():
     lens = np.array([args.ids], np.int32)
     hop = vhp.hop
     max_samples = args.ids * 12 * hop
-    wav_f32 = torch.empty(max_samples, dtype=torch.float32, device=dev)
-    wav_i16 = torch.empty(max_samples, dtype=torch.int16, device=dev)
+    conc = max(1, args.concurrency)
+    wav_f32 = [torch.empty(max_samples, dtype=torch.float32, device=dev) for _ in range(conc)]
+    wav_i16 = [torch.empty(max_samples, dtype=torch.int16, device=dev) for _ in range(conc)]
     s = ljspeech_audio_settings()
 
-    def step(i):
+    def step(i, slot=0):
         mel = eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, args.length_scale, None, 0, seed=1234 + i,
                                  audio_settings=s, flags=ffi.IN_DEVICE)
-        eng.hifigan_infer_raw(v, mel, wav_f32.data_ptr(), wav_i16.data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
+        eng.hifigan_infer_raw(v, mel, wav_f32[slot].data_ptr(), wav_i16[slot].data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
         f = int(mel.frames[0])
         mel.free()
         return f
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    pool = ThreadPoolExecutor(conc) if conc > 1 else None
+
+    def run_steps(lo, hi):
+        """K steps; with --concurrency C, C host threads pull utterances (the reference's
+        own ThreadPoolExecutor pattern, larynx/__init__.py:146), each on its own streams."""
+        if pool is None:
+            return sum(step(i) for i in range(lo, hi))
+        import queue
+
+        q = queue.SimpleQueue()
+        for i in range(lo, hi):
+            q.put(i)
+
+        def work(slot):
+            tot = 0
+            while True:
+                try:
+                    i = q.get_nowait()
+                except queue.Empty:
+                    return tot
+                tot += step(i, slot)
+
+        return sum(pool.map(work, range(conc)))
 
     def barrier():
         if world > 1:
@@ -182,9 +213,7 @@ def main():
     eng.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    frames = 0
-    for i in range(args.warmup, n_utts):
-        frames += step(i)
+    frames = sum(step(i) for i in range(args.warmup, n_utts))
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile()
@@ -196,19 +225,21 @@ def main():
     if args.serial_branches:
         eng.set_option("serial_branches", 1)
     barrier()
+    if conc > 1:
+        run_steps(0, min(args.warmup, conc))  # create the extra workers outside the timed region
+        barrier()
     t1 = time.perf_counter()
-    for i in range(args.warmup, n_utts):
-        step(i)
+    run_steps(args.warmup, n_utts)
     barrier()
     dt_clean = time.perf_counter() - t1
 
-    stats = torch.tensor([dt_clean, dt, float(frames)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt_clean, dt, float(frames), dt_latency], dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt_clean, dt = float(mx[0]), float(mx[1])
+        dt_clean, dt, dt_latency = float(mx[0]), float(mx[1]), float(mx[3])
         total_frames = float(sm[2])
     else:
         total_frames = float(frames)
@@ -245,9 +276,13 @@ def main():
                 "length_scale": args.length_scale,
                 "frames_per_utterance": fpu,
                 "parallelism": f"utterance-dp{world}",
+                "utterances_in_flight_per_gpu": conc,
             },
             "rtf": dt_clean * world / audio_s,
             "x_realtime_per_gpu": audio_s / (dt_clean * world),
+            "latency_ms_single_stream": 1e3 * dt_latency / K,
+            "rtf_single_stream": dt_latency * world / audio_s,
+            "x_realtime_single_stream": audio_s / (dt_latency * world),
             "end_to_end_tflops_per_gpu": algorithmic_flop(args.ids, fpu, args.quality) * K / dt_clean / 1e12,
             "roofline": {
                 "kernel": "conv_mfma_kernel (HiFi-GAN ResBlock convs)",

@@ -26,7 +26,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 enum ConvEpilogue {
   EPI_LINEAR = 0,    // y = [y +] alpha * (acc + bias [+ res]) ; optional row split into (y, y2)
-  EPI_GATE = 1,      // y[c] = tanh(acc[2p]) * sigmoid(acc[2p+1])      (glow_tts/utils.py:31-38)
+  EPI_GATE = 1,      // y[c] = tanh(acc[row i]) * sigmoid(acc[row i+16]) (glow_tts/utils.py:31-38)
   EPI_COUPLING = 2,  // y[c] = (res[c] - acc_m) * exp(-acc_logs)        (attentions.py:135-136)
   EPI_UPSAMPLE = 3,  // polyphase ConvTranspose1d scatter: row = co*u + r -> y[co][q*u + r - p]
 };
@@ -429,15 +429,17 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       }
     }
   } else if constexpr (EPI == EPI_GATE || EPI == EPI_COUPLING) {
-    static_assert(MB == 2, "paired epilogues need MB == 2");
-    // virtual tile pair p = blockIdx.y: block 0 holds rows c = p*32 + i of the
-    // first half (tanh / m), block 1 the matching rows of the second half.
-    float b0[16], b1[16];
+    static_assert(MB == 1, "paired epilogues use one 32-row tile: 16 rows of each half");
+    // virtual tile p = blockIdx.y holds rows c = 16p + i (i < 16) of the first half
+    // (tanh / m) in block rows 0..15 and the matching rows of the second half
+    // (sigmoid / logs) in block rows 16..31.  In the C/D map, block row i and row
+    // i + 16 sit in the SAME lane, registers r and r + 8 — the pair meets in registers.
+    float b0[8], b1[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + rbase;
+    for (int r = 0; r < 8; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + rbase;  // 0..15
       b0[r] = a.bias ? a.bias[mt0 * 32 + i] : 0.f;
-      b1[r] = a.bias ? a.bias[(mt0 + 1) * 32 + i] : 0.f;
+      b1[r] = a.bias ? a.bias[mt0 * 32 + 16 + i] : 0.f;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -445,37 +447,37 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       const bool tok = t < Lout;
       const int tc = tok ? t : Lout - 1;
       float* yb = a.y + (long long)b * a.y_bs + tc;
-      int off[16];
-      bool ok[16];
+      int off[8];
+      bool ok[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+      for (int r = 0; r < 8; ++r) {
+        const int c = blockIdx.y * 16 + (r & 3) + 8 * (r >> 2) + rbase;
         const bool cok = c < a.half;
         ok[r] = cok && tok;
         off[r] = (cok ? c : a.half - 1) * a.y_ld;
       }
-      float out[16];
+      float out[8];
       if constexpr (EPI == EPI_GATE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
           const float v0 = acc[0][nb][r] + b0[r];
-          const float v1 = acc[1][nb][r] + b1[r];
+          const float v1 = acc[0][nb][r + 8] + b1[r];
           out[r] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
         }
       } else {
         const float* rb = a.res + (long long)b * a.y_bs + tc;
-        float rv[16];
+        float rv[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+        for (int r = 0; r < 8; ++r) rv[r] = rb[off[r]];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
           const float v0 = acc[0][nb][r] + b0[r];
-          const float v1 = acc[1][nb][r] + b1[r];
+          const float v1 = acc[0][nb][r + 8] + b1[r];
           out[r] = (rv[r] - v0) * expf(-v1);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < 8; ++r)
         if (ok[r]) yb[off[r]] = out[r];
     }
   } else {  // EPI_UPSAMPLE

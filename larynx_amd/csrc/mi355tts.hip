@@ -88,17 +88,18 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
         d.has_bias, 8);
   } else if (layout == ROWS_PAIR) {
-    // virtual tiles (2p, 2p+1) = rows [32p, 32p+32) of the first and second half
+    // virtual 32-row tile p = rows [16p, 16p+16) of the first half followed by the
+    // same rows of the second half (see the paired epilogues of conv_mfma_kernel)
     const int half = half_or_up;
-    const int pairs = (half + 31) / 32;
-    d.MB = 2;
+    const int ptiles = (half + 15) / 16;
+    d.MB = 1;
     p = pack_conv(
-        pairs * 64, 2, Cin, K,
+        ptiles * 32, 1, Cin, K,
         [&](int v) {
           const int tile = v / 32, i = v % 32;
-          const int c = (tile / 2) * 32 + i;
+          const int c = tile * 16 + (i & 15);
           if (c >= half) return -1;
-          return (tile & 1) * half + c;
+          return (i >> 4) * half + c;
         },
         [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
         d.has_bias, 8);
@@ -472,12 +473,14 @@ template <> struct ConvCfg<7> { static constexpr int HALO = 76; };
 template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 
 // Tile shapes (all 512 threads):
+//   S2    : 1 time-wave  x 8 k-groups, 64 columns, 2 column blocks per wave (weights fetched once per workgroup)
+//   M2    : 2 time-waves x 4 k-groups, 128 columns, 2 column blocks per wave
 //   FLAT  : 4 time-waves x 1 k-group (256 threads), 128 columns — short reductions (C_in*K <= 512): no k-split, no LDS sum
 //   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
 //   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
 //   NB1   : 4 time-waves x 2 k-groups, 128 columns
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_FLAT = 4 };
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_FLAT = 4, TILE_S2 = 5, TILE_M2 = 6, TILE_LAST = 6 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -485,33 +488,38 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   constexpr int HALO = ConvCfg<K>::HALO;
   constexpr int CI_BIG = (K == 1) ? 64 : (K <= 5) ? 32 : 16;
   constexpr int CI_SMALL = (K == 1) ? 64 : 32;
+  constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_COUPLING);
   // the staged tile starts at the 4-aligned column t0 - roundup(pad, 4)
   if ((K - 1) * a.dil + ((4 - a.pad % 4) % 4) > HALO)
     return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
-  if (MB == 2) {
-    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 2, 1, 4, 1, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
-    else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
-    return 0;
-  }
-  if constexpr (EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE) {
+  if (MB == 1) {
     if (shape == TILE_FLAT) launch_conv_inst<K, 32, 1, 1, 4, 1, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_S2) launch_conv_inst<K, 64, 1, 2, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_M2) launch_conv_inst<K, 32, 1, 2, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
-  return fail(MI355TTS_ERR_INVALID, "paired epilogue needs MB == 2");
+  if constexpr (!PAIRED) {
+    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 2, 1, 4, 1, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_S2) launch_conv_inst<K, 64, 2, 2, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_M2) launch_conv_inst<K, 32, 2, 2, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
+    return 0;
+  }
+  return fail(MI355TTS_ERR_INVALID, "paired epilogues run on 32-row tiles (MB == 1)");
 }
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
 // template instance.  n_max = largest GEMM-N extent over the batch rows.
 static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
-                       hipStream_t stream = nullptr) {
+                       hipStream_t stream = nullptr, int min_tiles = 1024) {
   if (n_max <= 0 || B <= 0) return 0;
   if (epi == EPI_LINEAR && a.split > 0 && a.split < c.rows && (a.split % 32))
     return fail(MI355TTS_ERR_INVALID, "row split %d must be a multiple of 32", a.split);
@@ -522,13 +530,23 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   a.rows = c.rows;
   int MB = c.MB;
   int ytiles = c.mtiles / MB;
-  // Tile shape: the largest tile that still yields >= 1024 workgroups (4 per CU: the
-  // measured sweet spot of tools/conv_sweep.py), otherwise the smallest tile.
+  // Tile shape: the largest tile that still yields >= min_tiles workgroups, otherwise the
+  // smallest tile.  1024 (4 per CU) is the measured sweet spot for a kernel that has the
+  // chip to itself (tools/conv_sweep.py); the three concurrent MRF chains ask for 300
+  // each — together they fill the chip, and the bigger tiles run closer to the MFMA rate.
   auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
+  long long want = min_tiles;
+  if (cls == KC_RESBLOCK) {
+    static const int rb_want = [] {
+      const char* e = std::getenv("MI355TTS_RB_MIN_TILES");
+      return e ? std::atoi(e) : 0;
+    }();
+    if (rb_want > 0) want = rb_want;
+  }
   int shape = TILE_TINY;
-  if (tiles(256) >= 1024) shape = TILE_NB2;
-  else if (tiles(128) >= 1024) shape = TILE_NB1;
-  else if (tiles(64) >= 1024) shape = TILE_SMALL;
+  if (tiles(256) >= want) shape = TILE_NB2;
+  else if (tiles(128) >= want) shape = TILE_NB1;
+  else if (tiles(64) >= want) shape = TILE_SMALL;
   {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
     static const int forced = [] {
       const char* e = std::getenv("MI355TTS_FORCE_TILE");
@@ -536,8 +554,10 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     }();
     int f = forced;
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
+    if (cls == KC_RESBLOCK)
+      if (const char* rb = std::getenv("MI355TTS_RB_TILE")) f = std::atoi(rb);  // tuning knob: ResBlock convs only
     if (g_pin_tile >= 0) f = g_pin_tile;
-    if (f >= TILE_SMALL && f <= TILE_FLAT) shape = f;
+    if (f >= TILE_SMALL && f <= TILE_LAST) shape = f;
   }
   // a launch that cannot even give every CU one workgroup: halve the row tile too
   // (32-row m-tiles are independent in the packed weights; paired epilogues need both)
@@ -545,7 +565,7 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     MB = 1;
     ytiles = (c.rows + 31) / 32;
   }
-  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  const int T_T = shape == TILE_TINY ? 32 : (shape == TILE_SMALL || shape == TILE_S2) ? 64 : (shape == TILE_NB2 ? 256 : 128);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   hipStream_t s = stream ? stream : w->stream;
@@ -1476,6 +1496,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
     HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
   }
+  const int rb_tiles = concurrent ? 300 : 1024;
   const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
   size_t o_buf[16];
@@ -1559,7 +1580,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
         if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
           ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
           c.in_slope = 0.1f;
           c.res = rin;
@@ -1567,7 +1588,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
             c.alpha = inv_nk;
             c.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
+          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
         } else {  // ResBlock2.forward, models.py:136-141
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
@@ -1576,7 +1597,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
             a.alpha = inv_nk;
             a.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
         }
         rin = dst;
       }

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
   __shared__ float S[32 * ATTM_PS];
   __shared__ float vs[ATT_MAXDK * 65];
   __shared__ float relS[32 * 33];
+  __shared__ float evs[ATT_MAXW * ATT_MAXDK];
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int P = len[b];
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
   const int rbase = 4 * half;
   const int iq = min(i0 + col, P - 1);  // this lane's query column for A operands (clamped)
 
+  for (int e = threadIdx.x; e < ATT_MAXW * ATT_MAXDK; e += 256) {
+    const int rr = e / ATT_MAXDK, c = e - rr * ATT_MAXDK;
+    evs[e] = (rr < nrel && c < dk) ? ev[rr * dk + c] : 0.f;  // consumed after several barriers
+  }
   // ---- phase 1: S[i][j] = scale * q_i . k_j  (M = queries, N = keys, K-dim = channels).
   // The query fragments are loaded once and stay in registers; every key block (and
   // one extra block whose "keys" are the 2w+1 relative-position embeddings,
@@ -376,27 +381,38 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
     if (wave < ncb) {
       const int c = min(wave * 32 + col, dk - 1);
       const int jn = min(64, nkb * 32 - j0);
-      for (int jj = 0; jj < jn; jj += 2) {
-        const float av = (wave * 32 + col < dk) ? vs[c * 65 + jj + half] : 0.f;
-        const float bv = S[col * ATTM_PS + j0 + jj + half];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int jj = 0; jj < jn; jj += 8) {  // jn is a multiple of 32
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = (wave * 32 + col < dk) ? vs[c * 65 + jj + 2 * u + half] : 0.f;
+          bv[u] = S[col * ATTM_PS + j0 + jj + 2 * u + half];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
       }
     }
   }
   // (dk <= 128 = 4 channel blocks, one per wave)
   if (wave >= ncb) return;
   // ---- relative values on the band + store: out[c][i]      (attentions.py:246-253)
+  // (Ev was staged into LDS at kernel start: no dependent global loads here)
   const int gi = i0 + col;  // this lane's query
+  float pband[ATT_MAXW];
+#pragma unroll
+  for (int rr = 0; rr < ATT_MAXW; ++rr) {
+    const int j = gi + rr - window;
+    const bool ok = rr < nrel && j >= 0 && j < P;
+    pband[rr] = ok ? S[col * ATTM_PS + (j < 0 ? 0 : (j >= P ? P - 1 : j))] : 0.f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = wave * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-    if (c >= dk || gi >= P) continue;
+    const int cc = c < dk ? c : dk - 1;
     float o = acc[r];
-    for (int rr = 0; rr < nrel; ++rr) {
-      const int j = gi + rr - window;
-      if (j >= 0 && j < P) o += S[col * ATTM_PS + j] * ev[rr * dk + c];
-    }
-    out[(long long)b * out_bs + (long long)(h * dk + c) * out_ld + gi] = o;
+#pragma unroll
+    for (int rr = 0; rr < ATT_MAXW; ++rr) o += pband[rr] * evs[rr * ATT_MAXDK + cc];
+    if (c < dk && gi < P) out[(long long)b * out_bs + (long long)(h * dk + c) * out_ld + gi] = o;
   }
 }
 
