@@ -224,7 +224,13 @@ def main():
     # carry the profiling events' overhead
     if args.serial_branches:
         eng.set_option("serial_branches", 1)
+    # single-stream latency (one utterance at a time), event-free
     barrier()
+    tl = time.perf_counter()
+    for i in range(args.warmup, n_utts):
+        step(i)
+    barrier()
+    dt_latency = time.perf_counter() - tl
     if conc > 1:
         run_steps(0, min(args.warmup, conc))  # create the extra workers outside the timed region
         barrier()

@@ -131,10 +131,14 @@ int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, const int32_t*
 /* ---- HiFi-GAN: replaces HiFiGanVocoder.mels_to_audio ------------------------
  * Consumes the vocoder-input mel; writes per row frames[b]*hop samples (tail up
  * to wav_ld zero-filled).  wav_f32 (optional) is the generator output before
- * audio_float_to_int16; wav_i16 (optional) after it.  wav_ld >= max_frames*hop. */
+ * audio_float_to_int16; wav_i16 (optional) after it.  wav_ld >= max_frames*hop.
+ * denoiser_strength > 0 additionally runs the reference's spectral-subtraction
+ * denoiser (larynx/hifi_gan.py:152-203, STFT helpers larynx/audio.py:232-306) on
+ * the device before the int16 conversion; its bias spectrum is computed once per
+ * vocoder from an all-zero mel, as `maybe_init_denoiser` does. */
 int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder);
-int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float* wav_f32, int16_t* wav_i16,
-                           int64_t wav_ld, uint32_t flags);
+int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                           float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags);
 
 /* ---- single operators (kernel-level parity tests, drop-in conv) ------------- */
 /* y[B][Cout][L] = act_out(bias + conv1d(lrelu_slope(x[B][Cin][L]), w[Cout][Cin][K], dilation, "same" padding)) */
@@ -143,6 +147,11 @@ int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L,
 /* y[B][Cout][L*stride] = bias + conv_transpose1d(lrelu_slope(x), w[Cin][Cout][K], stride, padding=(K-stride)/2) */
 int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const float* w,
                                  const float* bias, int Cout, int K, int stride, float in_slope, float* y);
+
+/* out[B][N] = denoise(wav[B][N], bias_spec[513], strength): the STFT kernels alone
+ * (host buffers), N a multiple of 256 and > 1024 */
+int mi355tts_op_denoise(mi355tts_ctx* ctx, const float* wav, int B, int64_t N, const float* bias_spec, float strength,
+                        float* out);
 
 /* Kernel micro-benchmark: `iters` back-to-back launches of the conv kernel on
  * device-resident random data of the given geometry (tile_shape -1 = the

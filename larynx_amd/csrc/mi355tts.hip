@@ -181,6 +181,10 @@ struct HifiModel {
   // [stage][kernel][dilation index]
   std::vector<std::vector<std::vector<HifiResConv>>> rb;
   int hop = 1;
+  // denoiser bias spectrum |STFT(generator(zeros))|[:, 0] (larynx/hifi_gan.py:181-203), built on first use
+  std::mutex bias_mu;
+  float* bias_spec = nullptr;
+  bool bias_ready = false;
 };
 
 static std::vector<std::pair<std::string, int64_t>> glow_manifest(const mi355tts_glow_hparams& h) {
@@ -680,8 +684,10 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
   }
   for (auto& kv : ctx->glow)
     if (kv.second->arena) hipFree(kv.second->arena);
-  for (auto& kv : ctx->hifi)
+  for (auto& kv : ctx->hifi) {
     if (kv.second->arena) hipFree(kv.second->arena);
+    if (kv.second->bias_spec) hipFree(kv.second->bias_spec);
+  }
   delete ctx;
 }
 
@@ -1027,6 +1033,7 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
   auto v = ctx->hifi.find(model);
   if (v != ctx->hifi.end()) {
     hipFree(v->second->arena);
+    if (v->second->bias_spec) hipFree(v->second->bias_spec);
     ctx->hifi.erase(v);
     return 0;
   }
@@ -1443,10 +1450,49 @@ extern "C" int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder) {
   return it->second->hop;
 }
 
-extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float* wav_f32,
-                                      int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
+static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
+  std::lock_guard<std::mutex> lk(hm->bias_mu);
+  if (hm->bias_ready) return 0;
+  const int M = hm->hp.num_mels, hop = hm->hop;
+  const int zf = 88;  // the reference's all-zero mel has 88 frames (hifi_gan.py:187,198)
+  const long long N = (long long)zf * hop;
+  if (N <= DN_FFT) return fail(MI355TTS_ERR_INVALID, "vocoder hop %d too small for the 1024-point denoiser STFT", hop);
+  HIPCHECK(hipSetDevice(ctx->device));
+  std::vector<float> zeros((size_t)M * zf, 0.f);
+  int32_t fr = zf;
+  mi355tts_mel* zm = nullptr;
+  CHECK(mi355tts_mel_from_buffer(ctx, zeros.data(), &fr, 1, M, zf, nullptr, 0, &zm));
+  float* dwav = nullptr;
+  float* bias = nullptr;
+  int rc = 0;
+  if (hipMalloc(&dwav, sizeof(float) * (size_t)N) != hipSuccess || hipMalloc(&bias, sizeof(float) * (DN_FFT / 2 + 1)) != hipSuccess)
+    rc = fail(MI355TTS_ERR_NOMEM, "hipMalloc denoiser bias");
+  if (!rc) rc = mi355tts_hifigan_infer(ctx, vocoder, zm, 0.f, dwav, nullptr, N, MI355TTS_OUT_DEVICE);
+  if (!rc) {
+    Worker* w = nullptr;
+    rc = acquire_worker(ctx, &w);
+    if (!rc) {
+      WorkerGuard guard{ctx, w};
+      hipLaunchKernelGGL(stft_denoise_kernel, dim3(1, 1), dim3(256), 0, w->stream, dwav, (long long)N, zm->frames_dev, hop,
+                         (const float*)nullptr, 0.f, (float*)nullptr, 1, bias);
+      if (hipStreamSynchronize(w->stream) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "denoiser bias kernel failed");
+    }
+  }
+  mel_destroy(zm);
+  if (dwav) hipFree(dwav);
+  if (rc) {
+    if (bias) hipFree(bias);
+    return rc;
+  }
+  hm->bias_spec = bias;
+  hm->bias_ready = true;
+  return 0;
+}
+
+extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                                      float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
   if (!ctx || !mel) return fail(MI355TTS_ERR_INVALID, "null argument");
-  const HifiModel* hm;
+  HifiModel* hm;
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->hifi.find(vocoder);
@@ -1458,6 +1504,15 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   const int B = mel->B, F = mel->max_frames, hop = hm->hop;
   const long long N = (long long)F * hop;
   if (wav_ld < N) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)wav_ld, N);
+  const bool denoise = denoiser_strength > 0.f && F > 0;
+  if (denoise) {
+    // the reference's STFT needs more than one 1024-sample frame per utterance
+    // (larynx/audio.py:232-249 raises on shorter input)
+    for (int b = 0; b < B; ++b)
+      if ((long long)mel->frames[b] * hop <= DN_FFT)
+        return fail(MI355TTS_ERR_INVALID, "utterance %d has %d frames: too short for the denoiser", b, mel->frames[b]);
+    CHECK(ensure_denoiser_bias(ctx, hm, vocoder));
+  }
   const bool out_dev = (flags & MI355TTS_OUT_DEVICE) != 0;
   if (F == 0) {
     if (!out_dev) {
@@ -1504,6 +1559,9 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   const size_t o_wav = cv.take(sizeof(float) * (size_t)B * Nld);
   const size_t o_i16 = cv.take(sizeof(short) * (size_t)B * Nld);
   const size_t o_peak = cv.take(sizeof(unsigned) * B);
+  const int Tmax = denoise ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0;
+  const size_t o_wav2 = cv.take(denoise ? sizeof(float) * (size_t)B * Nld : 0);
+  const size_t o_fbuf = cv.take(denoise ? sizeof(float) * (size_t)B * Tmax * DN_FFT : 0);
   CHECK(reserve(w, cv.pos));
   char* base = w->arena;
   float* buf[16];
@@ -1626,6 +1684,16 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     a.out_act = ACT_TANH;
     CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO));
   }
+  if (denoise) {  // HiFiGanVocoder.denoise (larynx/hifi_gan.py:171-179)
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    float* wav2 = (float*)(base + o_wav2);
+    float* fbuf = (float*)(base + o_fbuf);
+    hipLaunchKernelGGL(stft_denoise_kernel, dim3(Tmax, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, hm->bias_spec,
+                       denoiser_strength, fbuf, Tmax, (float*)nullptr);
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fbuf, Tmax, d_frames, hop, wav2, (long long)Nld,
+                       (long long)Nld);
+    wav = wav2;
+  }
   {
     ProfScope ps(ctx, w, KC_SMALL, 0);
     hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
@@ -1739,6 +1807,42 @@ extern "C" int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int 
 extern "C" int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const float* w,
                                             const float* bias, int Cout, int K, int stride, float in_slope, float* y) {
   return op_conv_common(ctx, x, B, Cin, L, nullptr, w, bias, Cout, K, stride, in_slope, 0, y, true);
+}
+
+extern "C" int mi355tts_op_denoise(mi355tts_ctx* ctx, const float* wav, int B, int64_t N, const float* bias_spec,
+                                   float strength, float* out) {
+  if (!ctx || !wav || !bias_spec || !out || B <= 0 || N <= DN_FFT || (N % DN_HOP))
+    return fail(MI355TTS_ERR_INVALID, "bad argument (N must be a multiple of 256 and > 1024)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  const int T = (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP);
+  Carver cv;
+  const size_t o_in = cv.take(sizeof(float) * (size_t)B * N);
+  const size_t o_out = cv.take(sizeof(float) * (size_t)B * N);
+  const size_t o_f = cv.take(sizeof(float) * (size_t)B * T * DN_FFT);
+  const size_t o_b = cv.take(sizeof(float) * (DN_FFT / 2 + 1));
+  const size_t o_fr = cv.take(sizeof(int) * B);
+  CHECK(reserve(w, cv.pos));
+  char* base = w->arena;
+  float* din = (float*)(base + o_in);
+  float* dout = (float*)(base + o_out);
+  float* fb = (float*)(base + o_f);
+  float* db = (float*)(base + o_b);
+  int* dfr = (int*)(base + o_fr);
+  hipStream_t s = w->stream;
+  std::vector<int> fr(B, (int)(N / DN_HOP));
+  HIPCHECK(hipMemcpyAsync(din, wav, sizeof(float) * (size_t)B * N, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(db, bias_spec, sizeof(float) * (DN_FFT / 2 + 1), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(dfr, fr.data(), sizeof(int) * B, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(stft_denoise_kernel, dim3(T, B), dim3(256), 0, s, din, (long long)N, dfr, DN_HOP, db, strength, fb, T,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fb, T, dfr, DN_HOP, dout, (long long)N, (long long)N);
+  HIPCHECK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)B * N, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
+  return 0;
 }
 
 extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, int dilation, int L,

@@ -604,6 +604,125 @@ __global__ void to_int16_kernel(const float* wav, long long bs, const int* frame
   }
 }
 
+// ---- spectral-subtraction denoiser -------------------
+// `HiFiGanVocoder.denoise` (larynx/hifi_gan.py:171-179) with the reference's own
+// STFT conventions (larynx/audio.py:232-269): 1024-point frames every 256 samples
+// for i in range(0, N - 1024, 256), symmetric np.hanning window on analysis AND
+// synthesis, no window-sum normalisation.  One workgroup = one frame: radix-2
+// FFT in LDS, |X| -= bias*strength (clamped at 0, phase kept), inverse FFT,
+// synthesis window; a second kernel overlap-adds the frames in frame order.
+constexpr int DN_FFT = 1024;
+constexpr int DN_HOP = 256;
+
+__device__ __forceinline__ int dn_brev10(int i) {
+  int r = 0;
+#pragma unroll
+  for (int b = 0; b < 10; ++b) r |= ((i >> b) & 1) << (9 - b);
+  return r;
+}
+
+__device__ __forceinline__ void dn_fft1024(float* re, float* im, const float* cs, const float* sn, int tid) {
+  // in-place radix-2 DIT on bit-reversed input; 512 butterflies per stage, 2 per thread
+  for (int s = 1; s <= 10; ++s) {
+    const int half = 1 << (s - 1);
+    const int stride = DN_FFT >> s;  // twiddle index step
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = tid + 256 * u;
+      const int pos = t & (half - 1);
+      const int i0 = ((t - pos) << 1) + pos;
+      const int i1 = i0 + half;
+      const float wr = cs[pos * stride], wi = sn[pos * stride];
+      const float tr = re[i1] * wr - im[i1] * wi;
+      const float ti = re[i1] * wi + im[i1] * wr;
+      const float ar = re[i0], ai = im[i0];
+      re[i1] = ar - tr;
+      im[i1] = ai - ti;
+      re[i0] = ar + tr;
+      im[i0] = ai + ti;
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int dn_num_frames(long long N) { return N > DN_FFT ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0; }
+
+// mag_out != nullptr: only write |X| of frame 0 (bias spectrum initialisation).
+__global__ __launch_bounds__(256) void stft_denoise_kernel(const float* wav, long long bs, const int* frames, int hop,
+                                                           const float* bias_spec, float strength, float* fbuf, int Tmax,
+                                                           float* mag_out) {
+  __shared__ float re[DN_FFT], im[DN_FFT], cs[DN_FFT / 2], sn[DN_FFT / 2], win[DN_FFT];
+  const int b = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
+  const long long N = (long long)frames[b] * hop;
+  if (n >= dn_num_frames(N)) return;
+  const float* x = wav + (long long)b * bs + (long long)n * DN_HOP;
+  for (int i = tid; i < DN_FFT; i += 256) {
+    const float w = 0.5f - 0.5f * cospif(2.0f * (float)i / (float)(DN_FFT - 1));  // np.hanning(1024)
+    win[i] = w;
+    const int j = dn_brev10(i);
+    re[j] = x[i] * w;
+    im[j] = 0.f;
+  }
+  for (int k = tid; k < DN_FFT / 2; k += 256) {
+    cs[k] = cospif((float)k / 512.0f);
+    sn[k] = -sinpif((float)k / 512.0f);
+  }
+  __syncthreads();
+  dn_fft1024(re, im, cs, sn, tid);
+  if (mag_out) {
+    for (int k = tid; k <= DN_FFT / 2; k += 256) mag_out[k] = sqrtf(re[k] * re[k] + im[k] * im[k]);
+    return;
+  }
+  // spectral subtraction on bins 0..512, mirrored onto the conjugate half; conj for the inverse
+  for (int k = tid; k <= DN_FFT / 2; k += 256) {
+    const float mag = sqrtf(re[k] * re[k] + im[k] * im[k]);
+    const float g = mag > 0.f ? fmaxf(mag - bias_spec[k] * strength, 0.f) / mag : 0.f;
+    const float xr = re[k] * g, xi = im[k] * g;
+    re[k] = xr;
+    im[k] = -xi;  // conj(X)
+    if (k > 0 && k < DN_FFT / 2) {
+      re[DN_FFT - k] = xr;
+      im[DN_FFT - k] = xi;  // conj of the mirrored bin conj(X[k])
+    }
+  }
+  __syncthreads();
+  // bit-reverse permutation in place, then the same forward transform: IFFT(X) = conj(FFT(conj X))/N
+  for (int i = tid; i < DN_FFT; i += 256) {
+    const int j = dn_brev10(i);
+    if (i < j) {
+      const float tr = re[i], ti = im[i];
+      re[i] = re[j];
+      im[i] = im[j];
+      re[j] = tr;
+      im[j] = ti;
+    }
+  }
+  __syncthreads();
+  dn_fft1024(re, im, cs, sn, tid);
+  float* fo = fbuf + ((long long)b * Tmax + n) * DN_FFT;
+  for (int i = tid; i < DN_FFT; i += 256) fo[i] = win[i] * re[i] * (1.0f / DN_FFT);
+}
+
+// out[s] = sum over the (up to 4) frames covering sample s, in frame order; length T*256 + 1024.
+__global__ void overlap_add_kernel(const float* fbuf, int Tmax, const int* frames, int hop, float* out, long long bs,
+                                   long long ld) {
+  const int b = blockIdx.y;
+  const long long N = (long long)frames[b] * hop;
+  const int T = dn_num_frames(N);
+  const long long len = T > 0 ? (long long)T * DN_HOP + DN_FFT : 0;
+  for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < ld; s += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (s < len) {
+      int n0 = (int)((s - (DN_FFT - 1) + DN_HOP - 1) / DN_HOP);
+      if (s < DN_FFT) n0 = 0;
+      int n1 = (int)(s / DN_HOP);
+      if (n1 > T - 1) n1 = T - 1;
+      for (int n = n0; n <= n1; ++n) acc += fbuf[((long long)b * Tmax + n) * DN_FFT + (s - (long long)n * DN_HOP)];
+    }
+    out[(long long)b * bs + s] = acc;
+  }
+}
+
 __global__ void zero_tail_kernel(float* wav, long long bs, long long ld, const int* frames, int hop) {
   const int b = blockIdx.y;
   const long long N = (long long)frames[b] * hop;

@@ -180,8 +180,9 @@ class Engine:
         )
         return MelBatch(self, out.value)
 
-    def hifigan_infer_raw(self, vocoder, mel: MelBatch, f32_ptr, i16_ptr, wav_ld, flags=0):
-        ffi.check(self.lib, self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, f32_ptr, i16_ptr, wav_ld, flags))
+    def hifigan_infer_raw(self, vocoder, mel: MelBatch, f32_ptr, i16_ptr, wav_ld, flags=0, denoiser_strength=0.0):
+        ffi.check(self.lib, self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, float(denoiser_strength), f32_ptr,
+                                                           i16_ptr, wav_ld, flags))
 
     def mel_from_numpy(self, mel: np.ndarray, frames=None, audio_settings=None) -> MelBatch:
         mel = np.ascontiguousarray(mel, np.float32)
@@ -205,7 +206,8 @@ class Engine:
             self._hops[vocoder] = ffi.check(self.lib, self.lib.mi355tts_hifigan_hop(self._ctx, vocoder))
         return self._hops[vocoder]
 
-    def hifigan_infer(self, vocoder: int, mel: MelBatch, want_float: bool = True, want_int16: bool = True):
+    def hifigan_infer(self, vocoder: int, mel: MelBatch, want_float: bool = True, want_int16: bool = True,
+                      denoiser_strength: float = 0.0):
         """Returns (wav_f32 [B, N] or None, wav_i16 [B, N] or None), N = max_frames*hop;
         row b holds frames[b]*hop samples followed by zeros."""
         n = mel.max_frames * self.hop(vocoder)
@@ -213,7 +215,7 @@ class Engine:
         i16 = np.zeros((mel.batch, n), np.int16) if want_int16 else None
         ffi.check(
             self.lib,
-            self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, ffi.ptr(f32), ffi.ptr(i16), n, 0),
+            self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, float(denoiser_strength), ffi.ptr(f32), ffi.ptr(i16), n, 0),
         )
         return f32, i16
 
@@ -234,6 +236,16 @@ class Engine:
             ),
         )
         return y
+
+    def denoise(self, wav: np.ndarray, bias_spec: np.ndarray, strength: float) -> np.ndarray:
+        wav = np.ascontiguousarray(wav, np.float32)
+        if wav.ndim == 1:
+            wav = wav[None]
+        bias = np.ascontiguousarray(bias_spec, np.float32)
+        out = np.zeros_like(wav)
+        ffi.check(self.lib, self.lib.mi355tts_op_denoise(self._ctx, wav.ctypes.data, wav.shape[0], wav.shape[1], bias.ctypes.data,
+                                                        float(strength), out.ctypes.data))
+        return out
 
     def conv_transpose1d(self, x, w, bias, stride, in_slope=1.0) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)

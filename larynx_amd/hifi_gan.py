@@ -24,9 +24,9 @@ class HipHiFiGanVocoder(VocoderModel):
     a `HipGlowTextToSpeech` returned, and gives back the same `int16 [N]`
     (`audio_float_to_int16(...).squeeze()`, :168-169).
 
-    The spectral-subtraction denoiser (`denoiser_strength > 0`, :152-179) is the
-    next row of SURVEY.md §8(f) and not on the HIP path yet: asking for it raises
-    rather than silently skipping it."""
+    `denoiser_strength > 0` (config or per-call `settings`, :152-156) runs the
+    reference's spectral-subtraction denoiser on the device (bias spectrum from an
+    all-zero mel, :181-203), before the int16 conversion."""
 
     def __init__(self, config: VocoderModelConfig, executor: typing.Optional[Executor] = None, device: int = 0,
                  library_path=None, state_dict=None, model_config: typing.Optional[dict] = None):
@@ -50,15 +50,15 @@ class HipHiFiGanVocoder(VocoderModel):
         strength = self.denoiser_strength
         if settings:
             strength = float(settings.get("denoiser_strength", strength))
-        if strength > 0:
-            raise NotImplementedError("denoiser_strength > 0 is not available on the HIP backend yet (SURVEY.md §8(f) rank 1)")
         batch = mels if isinstance(mels, MelBatch) else self.engine.mel_from_numpy(np.asarray(mels, np.float32))
-        _, i16 = self.engine.hifigan_infer(self.model_id, batch, want_float=False, want_int16=True)
+        _, i16 = self.engine.hifigan_infer(self.model_id, batch, want_float=False, want_int16=True,
+                                           denoiser_strength=max(strength, 0.0))
         n = int(batch.frames[0]) * self.engine.hop(self.model_id)
         return i16[0, :n] if batch.batch == 1 else i16
 
-    def mels_to_float(self, mels: ARRAY_OR_TENSOR) -> np.ndarray:
+    def mels_to_float(self, mels: ARRAY_OR_TENSOR, denoiser_strength: float = 0.0) -> np.ndarray:
         """Generator output before `audio_float_to_int16` (what waveform parity is defined on)."""
         batch = mels if isinstance(mels, MelBatch) else self.engine.mel_from_numpy(np.asarray(mels, np.float32))
-        f32, _ = self.engine.hifigan_infer(self.model_id, batch, want_float=True, want_int16=False)
+        f32, _ = self.engine.hifigan_infer(self.model_id, batch, want_float=True, want_int16=False,
+                                           denoiser_strength=denoiser_strength)
         return f32

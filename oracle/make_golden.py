@@ -37,7 +37,7 @@ sys.path.insert(0, str(REPO))
 from larynx_amd import hparams as HP  # noqa: E402
 from larynx_amd import synthetic  # noqa: E402
 from larynx_amd.audio import ljspeech_audio_settings  # noqa: E402
-from oracle import audio_np, glow_tts_np, hifi_gan_np  # noqa: E402
+from oracle import audio_np, denoise_np, glow_tts_np, hifi_gan_np  # noqa: E402
 
 
 def import_reference():
@@ -226,6 +226,26 @@ def main():
         report[name] = e
         print(name, json.dumps(e))
         assert e["mel"] < 2e-4 and e["wav_rms"] < 2e-5 and e["i16"] <= 1, e
+        extra = {}
+        if name == "ljspeech_medium_dave_ls12":
+            # denoiser (larynx/hifi_gan.py:152-203) through the reference's own STFT helpers
+            import torch
+
+            strength = 0.1
+            with torch.no_grad():
+                bias_audio = vmodel(torch.zeros(1, 80, 88)).squeeze(0).cpu().numpy()
+            bias_spec, _ = ra.transform(bias_audio)
+            bias_spec = bias_spec[:, :, 0][:, :, None]
+            spec, ang = ra.transform(wav[None])
+            den = ra.inverse(np.clip(spec - bias_spec * strength, a_min=0.0, a_max=None), ang)
+            den_i16 = ra.audio_float_to_int16(den).squeeze()
+            o_bias = denoise_np.bias_spectrum(lambda m: hifi_gan_np.hifigan_infer(vsd, vhp, m))
+            o_den = denoise_np.denoise(o_wav, o_bias, strength)
+            assert np.abs(o_bias - bias_spec[0, :, 0]).max() < 1e-4 * max(1.0, float(bias_spec.max()))
+            assert np.sqrt(np.mean((o_den - den[0]) ** 2)) < 2e-5
+            report[name]["denoise_rms"] = float(np.sqrt(np.mean((o_den - den[0]) ** 2)))
+            extra = dict(denoiser_strength=np.float32(strength), bias_spec=bias_spec[0, :, 0].astype(np.float32),
+                         wav_denoised=den[0][::3].astype(np.float32), wav_denoised_i16=den_i16[::3], wav_denoised_stride=np.int32(3))
         keep_wav = wav if len(wav) <= 80000 else None
         np.savez_compressed(
             GOLDEN / f"{name}.npz",
@@ -240,6 +260,7 @@ def main():
             logw=logw.astype(np.float32),
             glow=json.dumps(ghp.to_config()),
             vocoder=json.dumps(vhp.to_config()),
+            **extra,
         )
     (GOLDEN / "oracle_vs_reference.json").write_text(json.dumps(report, indent=1, sort_keys=True))
 

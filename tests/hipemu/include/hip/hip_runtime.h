@@ -222,6 +222,8 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline float cospif(float x) { return (float)std::cos(3.14159265358979323846 * (double)x); }
+static inline float sinpif(float x) { return (float)std::sin(3.14159265358979323846 * (double)x); }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -134,3 +134,19 @@ def test_glow_multi_block_attention(emu_engine):
         assert mel.frames[0] == ref.shape[1]
         np.testing.assert_allclose(mel.numpy("raw")[0], ref, atol=3e-5, rtol=1e-4)
     emu_engine.unload(g)
+
+
+def test_denoise_kernels_match_oracle(emu_engine):
+    """STFT -> spectral subtraction -> iSTFT (larynx/hifi_gan.py:171-179,
+    larynx/audio.py:232-289) against the float64 numpy restatement."""
+    from oracle import denoise_np
+
+    rng = np.random.default_rng(21)
+    wav = (rng.standard_normal((2, 256 * 14)) * 0.3).astype(np.float32)
+    bias = np.abs(rng.standard_normal(513)).astype(np.float32)
+    for strength in (0.0, 0.4):
+        got = emu_engine.denoise(wav, bias, strength)
+        for b in range(2):
+            ref = denoise_np.denoise(wav[b], bias, strength)
+            assert ref.shape[0] == wav.shape[1]
+            assert np.abs(got[b] - ref).max() < 2e-5, np.abs(got[b] - ref).max()

@@ -105,6 +105,32 @@ def test_serial_branch_schedule_matches_reference(gpu_engine):
     assert np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)) <= 2e-5
 
 
+def test_denoiser_matches_reference(gpu_engine):
+    """`denoiser_strength > 0` (CLI/server default path, larynx/hifi_gan.py:152-203)
+    against the reference's own numpy STFT helpers run on the reference generator."""
+    c = load_case("ljspeech_medium_dave_ls12")
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    wav, i16 = gpu_engine.hifigan_infer(v, mb, denoiser_strength=float(c["denoiser_strength"]))
+    st = int(c["wav_denoised_stride"])
+    assert wav.shape[1] == c["mel_voc"].shape[1] * 256
+    assert np.sqrt(np.mean((wav[0][::st] - c["wav_denoised"]) ** 2)) <= 1e-4
+    assert np.abs(i16[0][::st].astype(np.int32) - c["wav_denoised_i16"].astype(np.int32)).max() <= 2
+    plain, _ = gpu_engine.hifigan_infer(v, mb)
+    assert np.sqrt(np.mean((plain[0] - wav[0]) ** 2)) > 1e-3  # the denoiser did something
+
+
+def test_denoise_kernels(gpu_engine):
+    from oracle import denoise_np
+
+    rng = np.random.default_rng(21)
+    wav = (rng.standard_normal((2, 256 * 300)) * 0.3).astype(np.float32)
+    bias = np.abs(rng.standard_normal(513)).astype(np.float32)
+    got = gpu_engine.denoise(wav, bias, 0.4)
+    for b in range(2):
+        assert np.abs(got[b] - denoise_np.denoise(wav[b], bias, 0.4)).max() < 5e-5
+
+
 def test_vocoder_alone_on_reference_mel(gpu_engine):
     """`mels_to_audio` drop-in: host mel (already transformed) in, int16 out."""
     c = load_case("ljspeech_high_echo")
