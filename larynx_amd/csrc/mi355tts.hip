@@ -330,6 +330,9 @@ struct mi355tts_ctx {
   std::vector<Worker*> all_workers;
   bool profiling = false;
   bool serial_branches = false;
+  // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
+  // the whole device, which would serialise the concurrent per-utterance streams
+  std::vector<std::pair<void*, size_t>> mel_pool;
   struct Acc {
     long long launches = 0;
     double ms = 0, flop = 0;
@@ -344,6 +347,7 @@ struct mi355tts_mel {
   int* frames_dev = nullptr;
   std::vector<int32_t> frames;
   int max_frames = 0;
+  size_t raw_bytes = 0;  // allocation size of raw / voc (pool bookkeeping)
 };
 
 static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
@@ -682,6 +686,7 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
   }
+  for (auto& pe : ctx->mel_pool) hipFree(pe.first);
   for (auto& kv : ctx->glow)
     if (kv.second->arena) hipFree(kv.second->arena);
   for (auto& kv : ctx->hifi) {
@@ -1041,12 +1046,43 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
 }
 
 // ------------------------------------------------------------------ mel objects
+static void* pool_alloc(mi355tts_ctx* ctx, size_t bytes) {
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->mel_pool.size(); ++i)
+      if (ctx->mel_pool[i].second >= bytes && ctx->mel_pool[i].second <= 2 * bytes + (1 << 16) &&
+          (best < 0 || ctx->mel_pool[i].second < ctx->mel_pool[best].second))
+        best = i;
+    if (best >= 0) {
+      void* p = ctx->mel_pool[best].first;
+      ctx->mel_pool.erase(ctx->mel_pool.begin() + best);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  // the block remembers its size in the pool entry when it comes back; keep a header-free
+  // scheme by rounding deterministically (see pool_free)
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+static void pool_free(mi355tts_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (ctx->mel_pool.size() < 96) {
+    ctx->mel_pool.emplace_back(p, bytes);
+    return;
+  }
+  hipFree(p);
+}
+static size_t mel_bytes(const mi355tts_mel* m) { return (size_t)m->B * m->M * (size_t)std::max(m->ld, 1) * sizeof(float); }
 static void mel_destroy(mi355tts_mel* m) {
   if (!m) return;
-  hipSetDevice(m->ctx->device);
-  if (m->raw) hipFree(m->raw);
-  if (m->voc) hipFree(m->voc);
-  if (m->frames_dev) hipFree(m->frames_dev);
+  pool_free(m->ctx, m->raw, m->raw_bytes);
+  pool_free(m->ctx, m->voc, m->raw_bytes);
+  pool_free(m->ctx, m->frames_dev, sizeof(int) * (size_t)m->B);
   delete m;
 }
 extern "C" void mi355tts_mel_free(mi355tts_mel* m) { mel_destroy(m); }
@@ -1081,8 +1117,11 @@ static int mel_alloc(mi355tts_ctx* ctx, int B, int M, int ld, mi355tts_mel** out
   m->ld = ld;
   m->frames.assign(B, 0);
   const size_t n = (size_t)B * M * std::max(ld, 1) * sizeof(float);
-  if (hipMalloc(&m->raw, n) != hipSuccess || hipMalloc(&m->voc, n) != hipSuccess ||
-      hipMalloc(&m->frames_dev, sizeof(int) * B) != hipSuccess) {
+  m->raw_bytes = n;
+  m->raw = (float*)pool_alloc(ctx, n);
+  m->voc = (float*)pool_alloc(ctx, n);
+  m->frames_dev = (int*)pool_alloc(ctx, sizeof(int) * B);
+  if (!m->raw || !m->voc || !m->frames_dev) {
     mel_destroy(m);
     return fail(MI355TTS_ERR_NOMEM, "hipMalloc mel");
   }
@@ -1163,6 +1202,17 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   for (int b = 0; b < B; ++b) {
     if (id_lens[b] < 1 || id_lens[b] > ids_ld) return fail(MI355TTS_ERR_INVALID, "id_lens[%d]=%d outside [1,%d]", b, id_lens[b], ids_ld);
     Pmax = std::max(Pmax, id_lens[b]);
+  }
+  const bool in_dev_ids = (flags & MI355TTS_IN_DEVICE) != 0;
+  if (!in_dev_ids) {
+    // the reference's embedding lookup raises on an out-of-range id (glow_tts/models.py:119);
+    // device-resident ids cannot be checked without a sync and are clamped by the kernel instead
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < id_lens[b]; ++t) {
+        const int64_t id = ids[(size_t)b * ids_ld + t];
+        if (id < 0 || id >= h.num_symbols)
+          return fail(MI355TTS_ERR_INVALID, "phoneme id %lld at [%d][%d] outside [0,%d)", (long long)id, b, t, h.num_symbols);
+      }
   }
   HIPCHECK(hipSetDevice(ctx->device));
   Worker* w = nullptr;
@@ -1301,7 +1351,8 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     m->M = M;
     m->ld = 0;
     m->frames.assign(B, 0);
-    if (hipMalloc(&m->frames_dev, sizeof(int) * B) != hipSuccess) {
+    m->frames_dev = (int*)pool_alloc(ctx, sizeof(int) * B);
+    if (!m->frames_dev) {
       delete m;
       return fail(MI355TTS_ERR_NOMEM, "hipMalloc frames");
     }
@@ -1336,7 +1387,10 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   }
   {
     const size_t n = (size_t)B * M * Fld * sizeof(float);
-    if (hipMalloc(&mel->raw, n) != hipSuccess || hipMalloc(&mel->voc, n) != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc mel");
+    mel->raw_bytes = n;
+    mel->raw = (float*)pool_alloc(ctx, n);
+    mel->voc = (float*)pool_alloc(ctx, n);
+    if (!mel->raw || !mel->voc) return fail(MI355TTS_ERR_NOMEM, "hipMalloc mel");
   }
 
   // ---- decoder workspace (appended after the encoder's, which stays live)
@@ -1551,7 +1605,13 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
     HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
   }
-  const int rb_tiles = concurrent ? 300 : 1024;
+  // concurrent chains share the chip: 300 tiles each is the measured optimum for the two
+  // that overlap throughout; the longest chain (largest kernel) also runs alone at the
+  // end of every stage, so it gets finer tiles
+  static const int rb_base = [] { const char* e = std::getenv("MI355TTS_RB_BASE"); return e ? std::atoi(e) : 300; }();
+  static const int rb_long = [] { const char* e = std::getenv("MI355TTS_RB_LONG"); return e ? std::atoi(e) : 300; }();
+  int kmax = 0;
+  for (int j = 0; j < nk; ++j) kmax = std::max(kmax, h.resblock_kernel_sizes[j]);
   const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
   size_t o_buf[16];
@@ -1614,6 +1674,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     float* outs[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
       const int kk = h.resblock_kernel_sizes[j];
+      const int rb_tiles = !concurrent ? 1024 : (kk == kmax ? rb_long : rb_base);
       hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
       float *tb, *pa, *pb, *dst_last;
       if (concurrent) {

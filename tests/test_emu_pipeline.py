@@ -97,6 +97,8 @@ def test_errors_are_reported_not_crashed(emu_engine, tiny_models):
 
     with pytest.raises(Mi355ttsError):
         emu_engine.glow_infer(999, np.array([3, 4, 2]))
+    with pytest.raises(Mi355ttsError):  # id outside the voice's symbol table (the reference's embedding raises)
+        emu_engine.glow_infer(tiny_models["g"], np.array([3, HP.TINY_GLOW.num_symbols, 2]))
     with pytest.raises(Mi355ttsError):  # noise too short for the utterance
         emu_engine.glow_infer(tiny_models["g"], _ids(np.random.default_rng(1), 20), 0.667, 1.0,
                               noise=np.zeros((HP.TINY_GLOW.mel_channels, 4), np.float32))

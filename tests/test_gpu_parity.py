@@ -218,3 +218,51 @@ def test_threads_share_one_engine(gpu_engine):
         par = list(ex.map(run, rows))
     for a, b in zip(serial, par):
         assert np.array_equal(a, b)
+
+
+def test_long_utterance_and_three_resident_voices(gpu_engine):
+    """BASELINE config 5 shape: three voices (en V=46, de V=54, fr V=42) resident at
+    once, interleaved calls; plus a long (400-id) sentence at 'low' quality:
+    frame count = duration sum, every sample finite, per-voice results unaffected by
+    what else is loaded."""
+    s = ljspeech_audio_settings()
+    voices = {}
+    for name, ghp in (("en", HP.LJSPEECH), ("de", HP.THORSTEN), ("fr", HP.SIWIS)):
+        sd = synthetic.make_glow_state_dict(ghp, seed=1234 + len(name) * 7 + ord(name[0]))
+        voices[name] = (ghp, sd, gpu_engine.load_glow(ghp, sd))
+    _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_LOW)
+    rng = np.random.default_rng(3)
+    first = {}
+    for rnd in range(2):
+        for name, (ghp, sd, g) in voices.items():
+            ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(ord(name[0])), 40, ghp.num_symbols)
+            mel = gpu_engine.glow_infer(g, ids, 0.0, 1.0, audio_settings=s)
+            wav, _ = gpu_engine.hifigan_infer(v, mel)
+            if rnd == 0:
+                first[name] = wav.copy()
+                ref = glow_tts_np.glow_tts_infer(sd, ghp, ids, None, 0.0, 1.0)
+                assert int(mel.frames[0]) == ref.shape[1]
+                assert np.abs(mel.numpy("raw")[0] - ref).max() <= 5e-5
+            else:
+                assert np.array_equal(first[name], wav)
+    ghp, sd, g = voices["en"]
+    ids = synthetic.synthetic_phoneme_ids(rng, 400, ghp.num_symbols)
+    taps = {}
+    glow_tts_np.text_encoder(sd, ids, ghp, taps)
+    _, F, _ = glow_tts_np.durations_to_frames(taps["logw"], 1.0, 2)
+    mel = gpu_engine.glow_infer(g, ids, 0.667, 1.0, seed=5, audio_settings=s)
+    assert int(mel.frames[0]) == F
+    wav, i16 = gpu_engine.hifigan_infer(v, mel)
+    assert wav.shape[1] == F * 256 and np.isfinite(wav).all() and np.abs(wav).max() < 1.0
+    for name, (_, _, g) in voices.items():
+        gpu_engine.unload(g)
+
+
+def test_bad_ids_are_rejected(gpu_engine):
+    from larynx_amd.ffi import Mi355ttsError
+
+    (gsd, g), _ = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_MEDIUM)
+    with pytest.raises(Mi355ttsError):
+        gpu_engine.glow_infer(g, np.array([3, 46, 2]))
+    with pytest.raises(Mi355ttsError):
+        gpu_engine.glow_infer(g, np.array([3, -1, 2]))
