@@ -51,7 +51,7 @@ for full, st in stats.items():
                      fetch_kb=(f[1] / f[0]) if f else None, write_kb=(w[1] / w[0]) if w else None, mfma_util=util))
 rows.sort(key=lambda r: -r["pct"])
 with open(DST / f"{R}_summary.md", "w") as out:
-    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches`\n\n")
+    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches --concurrency 1`\n\n")
     out.write("Sources: `--kernel-trace --stats` (durations), separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and SQ passes "
               "(tools/profile_round.sh).  FETCH/WRITE are KB per dispatch as rocprofv3 reports them; on gfx950 FETCH_SIZE "
               "under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md §HBM) — the conv kernel reads its "
