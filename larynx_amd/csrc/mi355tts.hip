@@ -23,6 +23,7 @@
 
 #include "../../include/mi355tts.h"
 #include "conv_mfma.h"
+#include "resblock_pair.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -481,14 +482,13 @@ template <> struct ConvCfg<7> { static constexpr int HALO = 76; };
 template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 
 // Tile shapes (all 512 threads):
-//   S2    : 1 time-wave  x 8 k-groups, 64 columns, 2 column blocks per wave (weights fetched once per workgroup)
-//   M2    : 2 time-waves x 4 k-groups, 128 columns, 2 column blocks per wave
-//   FLAT  : 4 time-waves x 1 k-group (256 threads), 128 columns — short reductions (C_in*K <= 512): no k-split, no LDS sum
+// (2-column-block-per-wave variants at 64/128 columns and a 256-thread variant without
+//  k-split were measured in round 1 and never won; see profiles/r01_conv_sweep.txt)
 //   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
 //   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
 //   NB1   : 4 time-waves x 2 k-groups, 128 columns
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_FLAT = 4, TILE_S2 = 5, TILE_M2 = 6, TILE_LAST = 6 };
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -502,20 +502,14 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
     return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
   if (MB == 1) {
-    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 1, 1, 4, 1, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_S2) launch_conv_inst<K, 64, 1, 2, 1, 8, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_M2) launch_conv_inst<K, 32, 1, 2, 2, 4, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
   if constexpr (!PAIRED) {
-    if (shape == TILE_FLAT) launch_conv_inst<K, 32, 2, 1, 4, 1, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_S2) launch_conv_inst<K, 64, 2, 2, 1, 8, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_M2) launch_conv_inst<K, 32, 2, 2, 2, 4, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
     else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
@@ -573,7 +567,7 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     MB = 1;
     ytiles = (c.rows + 31) / 32;
   }
-  const int T_T = shape == TILE_TINY ? 32 : (shape == TILE_SMALL || shape == TILE_S2) ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
   const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   hipStream_t s = stream ? stream : w->stream;
@@ -606,6 +600,51 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     }
   }
   return rc;
+}
+
+// Fused ResBlock1 step (conv1 -> lrelu -> conv2 -> + x) for the 32/64-channel stages.
+// Returns 1 if the geometry is not covered (caller falls back to two conv launches).
+static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs,
+                       int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
+  static const int nb64 = [] { const char* e = std::getenv("MI355TTS_PAIR_NB64"); return e ? std::atoi(e) : 1; }();  // measured: 128-column tiles win at C = 64
+  const int C = c1.Cout, K = c1.K;
+  if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
+      (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y)
+    return 1;
+  PairArgs a;
+  a.x = x;
+  a.y = y;
+  a.bs = bs;
+  a.ld = ld;
+  a.len = len;
+  a.len_mul = len_mul;
+  a.w1 = c1.w;
+  a.b1 = c1.bias;
+  a.w2 = c2.w;
+  a.b2 = c2.bias;
+  a.noct = c1.noct;
+  a.C = C;
+  a.dil = dil;
+  a.slope = 0.1f;
+  a.alpha = alpha;
+  a.accum = accum;
+  const int NB = (C == 32) ? 2 : nb64;
+  const int T2 = 128 * NB - (K - 1);
+  dim3 grid((Lmax + T2 - 1) / T2, 1, B);
+  const double flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
+  ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+#define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
+#define PAIR_K(KK)                                  \
+  if (C == 32) PAIR_LAUNCH(KK, 1, 2);               \
+  else if (NB == 2) PAIR_LAUNCH(KK, 2, 2);          \
+  else PAIR_LAUNCH(KK, 2, 1)
+  if (K == 3) { PAIR_K(3); }
+  else if (K == 7) { PAIR_K(7); }
+  else { PAIR_K(11); }
+#undef PAIR_K
+#undef PAIR_LAUNCH
+  return 0;
 }
 
 static ConvArgs base_args(const float* x, long long x_bs, int x_ld, const int* in_len, int in_mul, float* y, long long y_bs,
@@ -1697,6 +1736,16 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
         float* dst = last ? dst_last : ((d & 1) ? pb : pa);
         if (!dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
         if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
+          {
+            const float pa_alpha = (last && !concurrent) ? inv_nk : 1.0f;
+            const int pa_accum = (last && !concurrent) ? (j > 0) : 0;
+            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj);
+            if (fr < 0) return fr;
+            if (fr == 0) {
+              rin = dst;
+              continue;
+            }
+          }
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
           CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));

@@ -1,0 +1,278 @@
+// One ResBlock1 step of HiFi-GAN fused into a single kernel, for the narrow stages
+// (C = 32 / 64) where both convs of the pair have ALL their channels inside one
+// workgroup:
+//
+//   y = x + conv2_{K,d=1}( lrelu( conv1_{K,d}( lrelu(x) ) ) )      hifi_gan/models.py:91-98
+//
+// The intermediate never leaves the CU: conv1 is evaluated on T1 = T2 + (K-1)
+// columns (the halo conv2 needs is recomputed, (K-1)/T1 extra work), its
+// activated output is parked in LDS, conv2 consumes it from there.  Compared with
+// two conv_mfma launches this removes one launch, one prologue/epilogue, and the
+// write + re-read of a whole [C][L] plane — at C = 32/64 the un-fused pair moves
+// 100 MB per 2-7 GFLOP and is bound by cache bandwidth, not by the matrix cores.
+//
+// Same building blocks as conv_mfma.h: v_mfma_f32_32x32x2_f32 (exact f32), packed
+// A-fragment stream from L2 through a 3-deep register ring, activations staged with
+// 16-byte loads and the leaky-ReLU applied once on the way into LDS, 4 time-waves x
+// 2 k-groups per workgroup, k-groups summed through LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_mfma.h"
+
+namespace mi355tts {
+
+struct PairArgs {
+  const float* x;  // input = residual, [B][C][ld]
+  float* y;        // output, same geometry (must not alias x)
+  long long bs;
+  int ld;
+  const int* len;  // valid length of row b = len[b] * len_mul
+  int len_mul;
+  const float* w1;  // packed like conv_mfma's weights: [m-tile][octet][tap][64][4]
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  int noct;  // packed octets per m-tile (padded)
+  int C;
+  int dil;  // dilation of conv1 (conv2 has dilation 1)
+  float slope;
+  float alpha;  // y = [y +] alpha * (...): the serial MRF schedule accumulates here
+  int accum;
+};
+
+constexpr int PAIR_DMAX = 5;  // largest conv1 dilation the staged halo covers
+
+// One MFMA phase: acc[mb][nb] += sum over this k-group's (octet, tap) steps of
+// A-fragment x B-column.  `bt` points at this lane's first B element (row `half`, its
+// first column); rows are RS floats apart, tap k is k*dil columns to the right.
+template <int K, int CB, int NB, int NO>
+__device__ __forceinline__ void pair_mfma_phase(floatx16 (&acc)[CB][NB], const float4* const (&wq)[CB], int kg, const float* bt,
+                                                int RS, int dil) {
+  constexpr int S = NO * K;
+  auto a_index = [&](int q) -> long long {
+    if (q >= S) q = S - 1;
+    const int oi = q / K;
+    const int k = q - oi * K;
+    return (long long)(((kg + oi * 2) * K + k)) * 64;
+  };
+  float4 ar[3][CB];
+#pragma unroll
+  for (int mb = 0; mb < CB; ++mb) {
+    ar[0][mb] = wq[mb][a_index(0)];
+    ar[1][mb] = wq[mb][a_index(1)];
+  }
+  float bcur[4][NB], bnxt[4][NB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = bt[(kg * 8 + 2 * j) * RS + nb * 32];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int mb = 0; mb < CB; ++mb) ar[(s + 2) % 3][mb] = wq[mb][a_index(s + 2)];
+    if (s + 1 < S) {
+      const int oi = (s + 1) / K;
+      const int k = (s + 1) - oi * K;
+      const float* bp = bt + ((kg + oi * 2) * 8) * RS + k * dil;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bnxt[j][nb] = bp[(2 * j) * RS + nb * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < CB; ++mb) {
+        const float4 af = ar[s % 3][mb];
+        const float av = (j == 0) ? af.x : (j == 1) ? af.y : (j == 2) ? af.z : af.w;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[j][nb], acc[mb][nb], 0, 0, 0);
+      }
+    }
+    if (s + 1 < S) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = bnxt[j][nb];
+    }
+  }
+}
+
+template <int K, int CB, int NB>
+__global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
+  constexpr int C = CB * 32;
+  constexpr int WN = 4;
+  constexpr int T1 = WN * NB * 32;     // conv1 columns per workgroup
+  constexpr int P2 = (K - 1) / 2;      // conv2 "same" padding
+  constexpr int T2 = T1 - 2 * P2;      // output columns per workgroup
+  constexpr int XW = (T1 + (K - 1) * PAIR_DMAX + 4 + 3) & ~3;  // staged x row: tile + conv1 halo + alignment slack
+  constexpr int TW = (T1 + K + 3) & ~3;                        // parked conv1 row (+ slack for the masked tail reads)
+  constexpr int NO = (C / 8) / 2;      // octets per k-group
+  constexpr int NF4 = C * (XW / 4);
+  constexpr int NE = (NF4 + 511) / 512;
+  constexpr int RED = WN * NB * 16 * 64;  // one m-block of every time-wave
+  static_assert(C * XW >= RED, "reduction scratch must fit in the x tile");
+
+  __shared__ float xs[C * XW];
+  __shared__ float ts[C * TW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave & 3;
+  const int kg = wave >> 2;
+  const int col = lane & 31, half = lane >> 5;
+  const int rbase = 4 * half;
+  const int b = blockIdx.z;
+  const int L = a.len[b] * a.len_mul;
+  const int j0 = blockIdx.x * T2;  // first output column of this workgroup
+  if (j0 >= L) return;
+  const int gt0 = j0 - P2;                  // global column of parked-tile column 0
+  const int p1 = (K - 1) * a.dil / 2;       // conv1 "same" padding
+  const int gx0 = (gt0 - p1) & ~3;          // 4-aligned global column of staged-tile column 0
+  const int shift = (gt0 - p1) - gx0;
+  const float* xb = a.x + (long long)b * a.bs;
+  const float slope = a.slope;
+
+  // ---- phase 0: stage lrelu(x) for all C channels, 16-byte loads, branch-free
+  {
+    const int ld_last4 = a.ld - 4;
+    float4 pre[NE];
+    int off[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 512 * i;
+      const int row = e / (XW / 4), f = e - row * (XW / 4);
+      const int c0 = gx0 + 4 * f;
+      off[i] = (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0));
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + off[i]);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 512 * i;
+      const int row = e / (XW / 4), f = e - row * (XW / 4);
+      const int c0 = gx0 + 4 * f;
+      float4 v = pre[i];
+      v.x = (c0 >= 0 && c0 < L) ? v.x : 0.f;
+      v.y = (c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+      v.z = (c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+      v.w = (c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+      v.x = v.x > 0.f ? v.x : v.x * slope;
+      v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope;
+      v.w = v.w > 0.f ? v.w : v.w * slope;
+      if (e < NF4) reinterpret_cast<float4*>(xs)[e] = v;
+      (void)row;
+    }
+  }
+  __syncthreads();
+
+  const float4* wq1[CB];
+  const float4* wq2[CB];
+#pragma unroll
+  for (int mb = 0; mb < CB; ++mb) {
+    wq1[mb] = reinterpret_cast<const float4*>(a.w1) + (long long)mb * a.noct * K * 64 + lane;
+    wq2[mb] = reinterpret_cast<const float4*>(a.w2) + (long long)mb * a.noct * K * 64 + lane;
+  }
+  floatx16 acc[CB][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  };
+  // sum the two k-groups through LDS (scratch aliases the x tile, dead by then), one
+  // m-block per round; group 0 continues with the full sums
+  auto reduce_groups = [&]() {
+    float* red = xs;
+#pragma unroll
+    for (int mb = 0; mb < CB; ++mb) {
+      __syncthreads();
+      if (kg == 1) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((wn * NB + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][nb][r] += red[((wn * NB + nb) * 16 + r) * 64 + lane];
+      }
+    }
+  };
+
+  // ---- phase 1: conv1 (dilation d) on T1 columns
+  zero_acc();
+  pair_mfma_phase<K, CB, NB, NO>(acc, wq1, kg, xs + half * XW + shift + wn * (NB * 32) + col, XW, a.dil);
+  reduce_groups();
+  if (kg == 0) {
+    // park lrelu(conv1 + bias); columns outside the sequence are conv2's ZERO padding
+#pragma unroll
+    for (int mb = 0; mb < CB; ++mb) {
+      float bb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[r] = a.b1[mb * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int jj = (wn * NB + nb) * 32 + col;
+        const int g = gt0 + jj;
+        const bool inside = g >= 0 && g < L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+          float v = acc[mb][nb][r] + bb[r];
+          v = v > 0.f ? v : v * slope;
+          ts[row * TW + jj] = inside ? v : 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: conv2 (dilation 1) on the parked tile
+  zero_acc();
+  pair_mfma_phase<K, CB, NB, NO>(acc, wq2, kg, ts + half * TW + wn * (NB * 32) + col, TW, 1);
+  reduce_groups();
+  if (kg != 0) return;
+  // ---- epilogue: + bias + residual, batched loads from clamped addresses
+#pragma unroll
+  for (int mb = 0; mb < CB; ++mb) {
+    float bb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[r] = a.b2[mb * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int jj = (wn * NB + nb) * 32 + col;
+      const int g = j0 + jj;
+      const bool tok = jj < T2 && g < L;
+      const int gc = g < L ? g : L - 1;
+      const float* rb = xb + gc;
+      float* yb = a.y + (long long)b * a.bs + gc;
+      float rv[16], v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = rb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (acc[mb][nb][r] + bb[r] + rv[r]) * a.alpha;
+      if (a.accum) {
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = yb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += ov[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tok) yb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld] = v[r];
+    }
+  }
+}
+
+}  // namespace mi355tts

@@ -211,6 +211,17 @@ TINY_HIFIGAN_RB2 = HifiGanHParams(
 )
 
 
+# stages of 64 and 32 channels: exercises the fused ResBlock-pair kernel on the emulator
+TINY_HIFIGAN_PAIR = HifiGanHParams(
+    upsample_rates=(2, 2),
+    upsample_kernel_sizes=(4, 4),
+    upsample_initial_channel=128,
+    resblock_kernel_sizes=(3, 11),
+    resblock_dilation_sizes=((1, 3), (5, 1)),
+    num_mels=16,
+)
+
+
 def load_config_json(path: typing.Union[str, Path]) -> typing.Dict[str, typing.Any]:
     with open(path, "r", encoding="utf-8") as f:
         return json.load(f)

@@ -52,7 +52,7 @@ def test_conv_transpose1d_matches_oracle(emu_engine, Cin, Cout, K, u, L):
     np.testing.assert_allclose(y[0], ref, rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
 @pytest.mark.parametrize("Cin,Cout,K,dil,L", [(24, 40, 3, 3, 300), (16, 16, 11, 5, 520), (40, 33, 1, 1, 290), (16, 72, 7, 1, 300)])
 def test_conv1d_every_tile_shape(emu_engine, monkeypatch, shape, Cin, Cout, K, dil, L):
     """The launcher picks the tile shape from the problem size; pin each one."""
@@ -66,7 +66,7 @@ def test_conv1d_every_tile_shape(emu_engine, monkeypatch, shape, Cin, Cout, K, d
     np.testing.assert_allclose(y[0], ref, rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
 def test_conv_transpose1d_every_tile_shape(emu_engine, monkeypatch, shape):
     monkeypatch.setenv("MI355TTS_FORCE_TILE_DYNAMIC", str(shape))
     rng = np.random.default_rng(shape)

@@ -152,3 +152,32 @@ def test_denoise_kernels_match_oracle(emu_engine):
             ref = denoise_np.denoise(wav[b], bias, strength)
             assert ref.shape[0] == wav.shape[1]
             assert np.abs(got[b] - ref).max() < 2e-5, np.abs(got[b] - ref).max()
+
+
+@pytest.mark.parametrize("serial", [0, 1])
+def test_fused_resblock_pair_kernel(emu_engine, serial):
+    """Stages of 64 and 32 channels run conv1 -> lrelu -> conv2 -> +x as ONE kernel
+    (csrc/resblock_pair.h): several tiles per row, ragged batch, both MRF schedules."""
+    hp = HP.TINY_HIFIGAN_PAIR
+    sd = synthetic.make_hifigan_state_dict(hp, seed=31)
+    v = emu_engine.load_hifigan(hp, sd)
+    rng = np.random.default_rng(32)
+    frames = np.array([150, 67], np.int32)
+    melin = (rng.standard_normal((2, hp.num_mels, 150)) * 2).astype(np.float32)
+    mb = emu_engine.mel_from_numpy(melin, frames)
+    emu_engine.set_option("serial_branches", serial)
+    emu_engine.set_profiling(True)
+    emu_engine.profile_reset()
+    try:
+        f32, _ = emu_engine.hifigan_infer(v, mb)
+        launches = emu_engine.profile()["conv_mfma.hifigan_resblock"]["launches"]
+    finally:
+        emu_engine.set_option("serial_branches", 0)
+        emu_engine.set_profiling(False)
+    assert launches == 2 * 2 * 2  # stages x kernels x dilations: one fused launch per conv PAIR
+    for b in range(2):
+        ref = hifi_gan_np.hifigan_infer(sd, hp, melin[b, :, : frames[b]])
+        n = frames[b] * hp.hop
+        assert np.sqrt(np.mean((f32[b, :n] - ref) ** 2)) < 1e-5
+        assert np.all(f32[b, n:] == 0)
+    emu_engine.unload(v)

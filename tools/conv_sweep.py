@@ -10,7 +10,7 @@ from larynx_amd.engine import Engine  # noqa: E402
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 624
 eng = Engine(0)
-SHAPES = (3, 0, 5, 1, 6, 2)
+SHAPES = (3, 0, 1, 2)
 layers = []
 for stage, (C, mul) in enumerate([(256, 8), (128, 64), (64, 128), (32, 256)]):
     for K in (3, 7, 11):
