@@ -77,6 +77,12 @@ struct ConvArgs {
   int up;
   int up_pad;
   int half;
+  // EPI_COUPLING only, optional: InvConvNear (pre-inverted 4x4, n_split = 4) + ActNorm
+  // reverse fused behind the coupling — z0 = first-half rows of the same tensor
+  float* mix_x0;           // base of the flow tensor (first half), geometry of y
+  const float* mix_w;      // [4][4] inverse weight
+  const float* mix_bias;   // [2*half] ActNorm bias
+  const float* mix_scale;  // [2*half] exp(-logs)
   // micro-benchmark ablations (tools/conv_probe.py; results are WRONG when set):
   // bit0 = no activation staging after chunk 0, bit1 = no A-fragment loads after
   // the prologue, bit2 = no per-chunk barrier
@@ -474,6 +480,40 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
           const float v0 = acc[0][nb][r] + b0[r];
           const float v1 = acc[0][nb][r + 8] + b1[r];
           out[r] = (rv[r] - v0) * expf(-v1);
+        }
+        if (a.mix_w) {
+          // InvConvNear reverse + ActNorm reverse (glow_tts/layers.py:238-272, 192-194) on the
+          // channel groups {2k, 2k+1, half+2k, half+2k+1}: registers (r, r+1), r even, hold the
+          // freshly coupled second-half pair; the first-half pair is fetched, all four are
+          // mixed with the pre-inverted 4x4 and written back normalised.
+          float* x0b = a.mix_x0 + (long long)b * a.y_bs + tc;
+          float w[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) w[i] = a.mix_w[i];
+          float xa[4], xb2[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            xa[q] = x0b[off[2 * q]];
+            xb2[q] = x0b[off[2 * q + 1]];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = 2 * q;
+            const int c0 = blockIdx.y * 16 + (r & 3) + 8 * (r >> 2) + rbase;  // even channel 2k
+            const int cc = c0 < a.half ? c0 : a.half - 2;
+            const float in0 = xa[q], in1 = xb2[q], in2 = out[r], in3 = out[r + 1];
+            float o[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[m] = w[m * 4 + 0] * in0 + w[m * 4 + 1] * in1 + w[m * 4 + 2] * in2 + w[m * 4 + 3] * in3;
+            const float y0 = (o[0] - a.mix_bias[cc]) * a.mix_scale[cc];
+            const float y1 = (o[1] - a.mix_bias[cc + 1]) * a.mix_scale[cc + 1];
+            out[r] = (o[2] - a.mix_bias[a.half + cc]) * a.mix_scale[a.half + cc];
+            out[r + 1] = (o[3] - a.mix_bias[a.half + cc + 1]) * a.mix_scale[a.half + cc + 1];
+            if (ok[r]) {
+              x0b[off[r]] = y0;
+              x0b[off[r + 1]] = y1;
+            }
+          }
         }
       }
 #pragma unroll

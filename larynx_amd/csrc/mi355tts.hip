@@ -1514,7 +1514,15 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
       ConvArgs a = base_args(skip, bsD, F2, d_f2, 1, z + (size_t)half * F2, bsZ, F2, d_f2, 1, 1, 0);
       a.res = z + (size_t)half * F2;
       a.half = half;
+      const bool fuse_mix = h.n_split == 4 && (half % 2) == 0;
+      if (fuse_mix) {  // InvConvNear + ActNorm ride in the coupling conv's epilogue
+        a.mix_x0 = z;
+        a.mix_w = A + Bk.winv;
+        a.mix_bias = A + Bk.an_bias;
+        a.mix_scale = A + Bk.an_scale;
+      }
       CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV));
+      if (fuse_mix) continue;
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
