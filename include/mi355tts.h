@@ -123,7 +123,7 @@ int mi355tts_mel_max_frames(const mi355tts_mel* mel);
 int mi355tts_mel_frames(const mi355tts_mel* mel, int32_t* frames /* [B] */);
 /* which: 0 = raw GlowTTS output, 1 = vocoder input.  dst is host [B][M][ld], ld >= max_frames */
 int mi355tts_mel_copy(const mi355tts_mel* mel, int which, float* dst, int ld);
-void mi355tts_mel_free(mi355tts_mel* mel);
+void mi355tts_mel_free(mi355tts_mel* mel); /* must precede mi355tts_destroy() of the owning context */
 /* Wrap a host (or device) mel [B][M][ld]; apply the mel transforms iff `audio` != NULL. */
 int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, const int32_t* frames, int B, int M, int ld,
                              const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);

@@ -6,6 +6,7 @@ import ctypes as C
 import json
 import threading
 import typing
+import weakref
 
 import numpy as np
 
@@ -22,6 +23,7 @@ class MelBatch:
     def __init__(self, engine: "Engine", handle: int):
         self._engine = engine
         self._h = C.c_void_p(handle)
+        engine._live_mels.add(self)
         lib = engine.lib
         self.batch = ffi.check(lib, lib.mi355tts_mel_batch(self._h))
         self.channels = ffi.check(lib, lib.mi355tts_mel_channels(self._h))
@@ -54,9 +56,12 @@ class MelBatch:
         return a if dtype is None else a.astype(dtype)
 
     def free(self):
+        """Return the device blocks to the engine's pool.  A mel must not outlive its
+        context: `Engine.close()` frees whatever is still alive first."""
         if self._h is not None:
-            self._engine.lib.mi355tts_mel_free(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            if self._engine._ctx is not None:
+                self._engine.lib.mi355tts_mel_free(h)
 
     def __del__(self):
         try:
@@ -74,9 +79,12 @@ class Engine:
         self._ctx = h
         self._lock = threading.Lock()
         self._hops: typing.Dict[int, int] = {}
+        self._live_mels: "weakref.WeakSet[MelBatch]" = weakref.WeakSet()
 
     def close(self):
         if self._ctx is not None:
+            for m in list(self._live_mels):  # their device blocks belong to this context
+                m.free()
             self.lib.mi355tts_destroy(self._ctx)
             self._ctx = None
 

@@ -181,3 +181,15 @@ def test_fused_resblock_pair_kernel(emu_engine, serial):
         assert np.sqrt(np.mean((f32[b, :n] - ref) ** 2)) < 1e-5
         assert np.all(f32[b, n:] == 0)
     emu_engine.unload(v)
+
+
+def test_mel_outliving_its_engine_is_harmless(emu_library):
+    """Closing an engine frees the mels it still owns; a later MelBatch.free()/__del__ is a no-op."""
+    from larynx_amd.engine import Engine
+
+    eng = Engine(0, library_path=emu_library)
+    g = eng.load_glow(HP.TINY_GLOW, synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7))
+    mel = eng.glow_infer(g, np.array([3, 5, 6, 2]), 0.0, 1.0)
+    eng.close()
+    mel.free()
+    del mel
