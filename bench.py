@@ -291,7 +291,7 @@ def main():
             "x_realtime_single_stream": audio_s / (dt_latency * world),
             "end_to_end_tflops_per_gpu": algorithmic_flop(args.ids, fpu, args.quality) * K / dt_clean / 1e12,
             "roofline": {
-                "kernel": "conv_mfma_kernel (HiFi-GAN ResBlock convs)",
+                "kernel": "HiFi-GAN ResBlock launches: conv_mfma_kernel (wide stages) + resblock_pair_kernel (32/64-channel stages)",
                 "bound": "mfma",
                 "achieved": dom_tf,
                 "peak": FP32_PEAK_TFLOPS,

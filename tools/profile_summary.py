@@ -63,14 +63,22 @@ with open(DST / f"{R}_summary.md", "w") as out:
         wk = f"{r['write_kb']:.0f}" if r["write_kb"] is not None else "-"
         mu = f"{100*r['mfma_util']:.1f}%" if r["mfma_util"] is not None else "-"
         out.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.2f} | {fk} | {wk} | {mu} |\n")
-# dominant kernel class = the LINEAR conv instances with K in {3,7,11} (HiFi-GAN ResBlocks)
-dom = [r for r in rows if r["kernel"].startswith("conv_mfma_kernel<") and r["kernel"].split("<")[1].split(",")[0] in ("3", "7", "11") and r["kernel"].rstrip(">").endswith(" 0")]
+# dominant kernel class = the HiFi-GAN ResBlock launches: LINEAR conv instances with K in {3,7,11}
+# (wide stages) plus the fused conv-pair kernel (32/64-channel stages)
+def is_dom(k):
+    if k.startswith("resblock_pair_kernel"):
+        return True
+    return k.startswith("conv_mfma_kernel<") and k.split("<")[1].split(",")[0] in ("3", "7", "11") and k.rstrip(">").endswith(" 0")
+
+
+dom = [r for r in rows if is_dom(r["kernel"])]
 n = sum(r["calls"] for r in dom)
 traffic = sum(r["calls"] * ((r["fetch_kb"] or 0) + (r["write_kb"] or 0)) for r in dom) * 1024.0 / n
 avg_us = sum(r["calls"] * r["avg_us"] for r in dom) / n
-json.dump({"round": R, "kernel_class": "conv_mfma_kernel LINEAR K in {3,7,11}", "dispatches": n, "avg_us": avg_us,
-           "hbm_bytes_per_launch_raw": traffic,
-           "note": "FETCH_SIZE+WRITE_SIZE (KB x 1024) per dispatch, separate PMC passes, no gfx950 x2 read correction applied"},
+json.dump({"round": R, "kernel_class": "HiFi-GAN ResBlock launches: conv_mfma_kernel LINEAR K in {3,7,11} + resblock_pair_kernel",
+           "dispatches": n, "avg_us": avg_us, "hbm_bytes_per_launch_raw": traffic,
+           "note": "FETCH_SIZE+WRITE_SIZE (KB x 1024) per dispatch, separate PMC passes, no gfx950 x2 read correction applied; "
+                   "the class also contains the GlowTTS encoder's few k=3 convs"},
           open(DST / f"{R}_roofline_traffic.json", "w"), indent=1)
 print(open(DST / f"{R}_summary.md").read())
 print(open(DST / f"{R}_roofline_traffic.json").read())
