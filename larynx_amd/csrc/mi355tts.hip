@@ -537,14 +537,7 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   // chip to itself (tools/conv_sweep.py); the three concurrent MRF chains ask for 300
   // each — together they fill the chip, and the bigger tiles run closer to the MFMA rate.
   auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
-  long long want = min_tiles;
-  if (cls == KC_RESBLOCK) {
-    static const int rb_want = [] {
-      const char* e = std::getenv("MI355TTS_RB_MIN_TILES");
-      return e ? std::atoi(e) : 0;
-    }();
-    if (rb_want > 0) want = rb_want;
-  }
+  const long long want = min_tiles;
   int shape = TILE_TINY;
   if (tiles(256) >= want) shape = TILE_NB2;
   else if (tiles(128) >= want) shape = TILE_NB1;
@@ -556,8 +549,6 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     }();
     int f = forced;
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
-    if (cls == KC_RESBLOCK)
-      if (const char* rb = std::getenv("MI355TTS_RB_TILE")) f = std::atoi(rb);  // tuning knob: ResBlock convs only
     if (g_pin_tile >= 0) f = g_pin_tile;
     if (f >= TILE_SMALL && f <= TILE_LAST) shape = f;
   }
@@ -607,7 +598,7 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
 static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs,
                        int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
-  static const int nb64 = [] { const char* e = std::getenv("MI355TTS_PAIR_NB64"); return e ? std::atoi(e) : 1; }();  // measured: 128-column tiles win at C = 64
+  const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
   if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
       (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y)
@@ -1493,8 +1484,6 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
       a.half = H;
-      dim3 dummy;
-      (void)dummy;
       CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV));
       ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       if (j < h.n_block_layers - 1) {
@@ -1652,13 +1641,9 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
     HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
   }
-  // concurrent chains share the chip: 300 tiles each is the measured optimum for the two
-  // that overlap throughout; the longest chain (largest kernel) also runs alone at the
-  // end of every stage, so it gets finer tiles
-  static const int rb_base = [] { const char* e = std::getenv("MI355TTS_RB_BASE"); return e ? std::atoi(e) : 300; }();
-  static const int rb_long = [] { const char* e = std::getenv("MI355TTS_RB_LONG"); return e ? std::atoi(e) : 300; }();
-  int kmax = 0;
-  for (int j = 0; j < nk; ++j) kmax = std::max(kmax, h.resblock_kernel_sizes[j]);
+  // concurrent chains share the chip: 300 tiles per launch measured best (sweeps of 80..1024,
+  // also per-chain values, in round 1: 6.6 ms vs 7.05 ms per utterance at 1024)
+  const int rb_tiles = concurrent ? 300 : 1024;
   const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
   size_t o_buf[16];
@@ -1721,7 +1706,6 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     float* outs[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
       const int kk = h.resblock_kernel_sizes[j];
-      const int rb_tiles = !concurrent ? 1024 : (kk == kmax ? rb_long : rb_base);
       hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
       float *tb, *pa, *pb, *dst_last;
       if (concurrent) {

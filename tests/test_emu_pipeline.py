@@ -193,3 +193,19 @@ def test_mel_outliving_its_engine_is_harmless(emu_library):
     eng.close()
     mel.free()
     del mel
+
+
+@pytest.mark.parametrize("n_ids", [1, 2, 3])
+def test_shortest_utterances(emu_engine, tiny_models, n_ids):
+    """One-, two- and three-id inputs (shorter than the attention window and than any
+    tile), and a one-frame mel through the vocoder."""
+    ids = np.array([3, 7, 2][:n_ids], np.int64)
+    ref = glow_tts_np.glow_tts_infer(tiny_models["gsd"], HP.TINY_GLOW, ids, None, 0.0, 1.0)
+    mel = emu_engine.glow_infer(tiny_models["g"], ids, 0.0, 1.0)
+    assert mel.frames[0] == ref.shape[1]
+    if ref.shape[1]:
+        np.testing.assert_allclose(mel.numpy("raw")[0], ref, atol=2e-5, rtol=1e-4)
+    one = (np.random.default_rng(n_ids).standard_normal((1, HP.TINY_HIFIGAN.num_mels, n_ids))).astype(np.float32)
+    f32, i16 = emu_engine.hifigan_infer(tiny_models["v"], emu_engine.mel_from_numpy(one))
+    refw = hifi_gan_np.hifigan_infer(tiny_models["vsd"], HP.TINY_HIFIGAN, one[0])
+    assert f32.shape[1] == refw.shape[0] and np.sqrt(np.mean((f32[0] - refw) ** 2)) < 1e-5

@@ -266,3 +266,17 @@ def test_bad_ids_are_rejected(gpu_engine):
         gpu_engine.glow_infer(g, np.array([3, 46, 2]))
     with pytest.raises(Mi355ttsError):
         gpu_engine.glow_infer(g, np.array([3, -1, 2]))
+
+
+@pytest.mark.parametrize("n_ids", [1, 2, 9])
+def test_shortest_utterances_full_size_models(gpu_engine, n_ids):
+    (gsd, g), (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_MEDIUM)
+    ids = np.array([3, 8, 4, 14, 3, 35, 3, 26, 2][:n_ids], np.int64)
+    s = ljspeech_audio_settings()
+    ref = glow_tts_np.glow_tts_infer(gsd, HP.LJSPEECH, ids, None, 0.0, 1.0)
+    mel = gpu_engine.glow_infer(g, ids, 0.0, 1.0, audio_settings=s)
+    assert int(mel.frames[0]) == ref.shape[1]
+    assert np.abs(mel.numpy("raw")[0] - ref).max() <= 5e-5
+    wav, _ = gpu_engine.hifigan_infer(v, mel)
+    refw = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_MEDIUM, audio_np.mel_to_vocoder_input(ref, s))
+    assert np.sqrt(np.mean((wav[0] - refw) ** 2)) <= 1e-4
