@@ -89,6 +89,21 @@ struct ConvArgs {
   int ablate;
 };
 
+// XCD-aware tile order.  The dispatcher deals workgroup `lin` to XCD `lin % 8`, each XCD
+// with its own L2.  Tiles that share input (the m-tiles of one time tile, and
+// neighbouring time tiles through the halo) should meet in ONE L2, so the linear id is
+// re-dealt: XCD x gets a contiguous run of tiles, m-tile fastest.  Bijective for any n
+// (MI355X_MICROARCH.md, T1); a wrong placement guess costs speed, never correctness.
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+  const int n = gx * gy;
+  const int lin = blockIdx.x + blockIdx.y * gx;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int q = n >> 3, r = n & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  ty = id % gy;
+  tx = id / gy;
+}
+
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
 __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs a) {
   // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
@@ -117,8 +132,10 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int wn = wave % WN;
   const int kg = wave / WN;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * T_T;
-  const int mt0 = blockIdx.y * MB;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int t0 = tile_x * T_T;
+  const int mt0 = tile_y * MB;
 
   const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
   const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       bool ok[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int c = blockIdx.y * 16 + (r & 3) + 8 * (r >> 2) + rbase;
+        const int c = tile_y * 16 + (r & 3) + 8 * (r >> 2) + rbase;
         const bool cok = c < a.half;
         ok[r] = cok && tok;
         off[r] = (cok ? c : a.half - 1) * a.y_ld;
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int r = 2 * q;
-            const int c0 = blockIdx.y * 16 + (r & 3) + 8 * (r >> 2) + rbase;  // even channel 2k
+            const int c0 = tile_y * 16 + (r & 3) + 8 * (r >> 2) + rbase;  // even channel 2k
             const int cc = c0 < a.half ? c0 : a.half - 2;
             const float in0 = xa[q], in1 = xb2[q], in2 = out[r], in3 = out[r + 1];
             float o[4];

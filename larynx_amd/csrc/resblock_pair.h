@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
   const int rbase = 4 * half;
   const int b = blockIdx.z;
   const int L = a.len[b] * a.len_mul;
-  const int j0 = blockIdx.x * T2;  // first output column of this workgroup
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
+  const int j0 = tile_x * T2;  // first output column of this workgroup
   if (j0 >= L) return;
   const int gt0 = j0 - P2;                  // global column of parked-tile column 0
   const int p1 = (K - 1) * a.dil / 2;       // conv1 "same" padding
