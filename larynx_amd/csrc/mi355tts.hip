@@ -521,8 +521,20 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
 // template instance.  n_max = largest GEMM-N extent over the batch rows.
 static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
-                       hipStream_t stream = nullptr, int min_tiles = 1024) {
+                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1) {
   if (n_max <= 0 || B <= 0) return 0;
+  if (B == 1 && host_len >= 0) {
+    // single utterance: the host already knows the row length, so the kernel need not
+    // start with a dependent global load of len[b]
+    if (a.in_len) {
+      a.in_const = host_len * a.in_mul;
+      a.in_len = nullptr;
+    }
+    if (a.out_len) {
+      a.out_const = host_len * a.out_mul;
+      a.out_len = nullptr;
+    }
+  }
   if (epi == EPI_LINEAR && a.split > 0 && a.split < c.rows && (a.split % 32))
     return fail(MI355TTS_ERR_INVALID, "row split %d must be a multiple of 32", a.split);
   a.w = c.w;
@@ -596,7 +608,8 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
 // Fused ResBlock1 step (conv1 -> lrelu -> conv2 -> + x) for the 32/64-channel stages.
 // Returns 1 if the geometry is not covered (caller falls back to two conv launches).
 static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs,
-                       int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s) {
+                       int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s,
+                       int host_len = -1) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
   const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
@@ -608,8 +621,9 @@ static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const De
   a.y = y;
   a.bs = bs;
   a.ld = ld;
-  a.len = len;
+  a.len = (B == 1 && host_len >= 0) ? nullptr : len;
   a.len_mul = len_mul;
+  a.len_const = host_len * len_mul;
   a.w1 = c1.w;
   a.b1 = c1.bias;
   a.w2 = c2.w;
@@ -1254,6 +1268,7 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   const int k = h.kernel_size, nh = h.n_heads;
   const int P = (Pmax + 3) & ~3;  // row stride
   const bool in_dev = (flags & MI355TTS_IN_DEVICE) != 0;
+  const int enc_host_len = B == 1 ? id_lens[0] : -1;
 
   // ---- encoder workspace
   Carver cv;
@@ -1298,20 +1313,20 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     const float* cur = x;
     for (int i = 0; i < h.prenet_layers; ++i) {
       ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
-      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
       cur = t2;
     }
     ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
     a.res = x;
-    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
   }
   for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
     const GlowLayer& L = gm->layers[l];
     {
       ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
-      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -1332,43 +1347,43 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     {
       ConvArgs a = base_args(t2, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, 0);
       a.res = x;
-      CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+      CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g1, A + L.b1, x, H, bsH, P, d_len, B, Pmax, 0);
     }
     {  // FFN, attentions.py:375-383
       ConvArgs a = base_args(x, bsH, P, d_len, 1, ffn, (long long)Fc * P, P, d_len, 1, 1, k / 2);
       a.out_act = ACT_RELU;
-      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
       ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
       c.res = x;
-      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
     }
   }
   {  // proj_m and the duration predictor (models.py:133-139, 39-49)
     ConvArgs a = base_args(x, bsH, P, d_len, 1, xm, (long long)M * P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
     float* d1 = ffn;
     float* d2 = ffn + (size_t)B * Fd * P;
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV));
+    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
   }
 
   // ---- durations -> frame counts (the one host sync of the path)
@@ -1467,6 +1482,7 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   }
   // frames/n_sqz is the decoder's time axis: len = frames[b] / nsq  -> use out_mul trick via a scaled length array
   // (frames are multiples of n_sqz; kernels take frames with a divisor where needed)
+  const int dec_host_len = B == 1 ? mel->frames[0] / nsq : -1;
   int* d_f2 = (int*)(base + o_len);  // reuse: id lengths are no longer needed after expansion
   {
     // d_f2[b] = frames[b] / nsq, computed on the host side of the sync above
@@ -1477,14 +1493,14 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     const GlowBlock& Bk = gm->blocks[blk];
     {  // CouplingBlock reverse (attentions.py:119-142): h = start(x0)
       ConvArgs a = base_args(z, bsZ, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
-      CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV));
+      CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
     }
     int dil = 1;
     for (int j = 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
       a.half = H;
-      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV));
+      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
       ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       if (j < h.n_block_layers - 1) {
         r.res = hbuf;  // x = x + res_skip[:H]
@@ -1496,7 +1512,7 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
       r.y2_bs = bsD;
       r.y2_ld = F2;
       r.accum2 = j > 0;
-      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV));
+      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
       dil *= h.dilation_rate;
     }
     {  // m, logs = end(wn_out);  z1 = (x1 - m) * exp(-logs)
@@ -1510,7 +1526,7 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
         a.mix_bias = A + Bk.an_bias;
         a.mix_scale = A + Bk.an_scale;
       }
-      CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV));
+      CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
       if (fuse_mix) continue;
     }
     {
@@ -1644,6 +1660,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   // concurrent chains share the chip: 300 tiles per launch measured best (sweeps of 80..1024,
   // also per-chain values, in round 1: 6.6 ms vs 7.05 ms per utterance at 1024)
   const int rb_tiles = concurrent ? 300 : 1024;
+  const int voc_host_len = B == 1 ? mel->frames[0] : -1;
   const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
   size_t o_buf[16];
@@ -1669,7 +1686,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   float* xu = buf[1];
   {  // conv_pre (models.py:187)
     ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * Fp, Fp, d_frames, 1, 1, 3);
-    CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO));
+    CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO, nullptr, 1024, voc_host_len));
   }
   auto set_inputs = [&](ConvArgs& a) {
     if (ncur > 1) {
@@ -1693,7 +1710,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
       a.in_slope = 0.1f;
       a.up = u;
       a.up_pad = (ku - u) / 2;
-      CHECK(launch_conv(ctx, w, hm->ups[i], a, EPI_UPSAMPLE, B, Lin + ku / u - 1, KC_UPSAMPLE));
+      CHECK(launch_conv(ctx, w, hm->ups[i], a, EPI_UPSAMPLE, B, Lin + ku / u - 1, KC_UPSAMPLE, nullptr, 1024, voc_host_len));
     }
     mul *= u;
     ch = cout;
@@ -1731,7 +1748,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           {
             const float pa_alpha = (last && !concurrent) ? inv_nk : 1.0f;
             const int pa_accum = (last && !concurrent) ? (j > 0) : 0;
-            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj);
+            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
             if (fr < 0) return fr;
             if (fr == 0) {
               rin = dst;
@@ -1740,7 +1757,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           }
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
           ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
           c.in_slope = 0.1f;
           c.res = rin;
@@ -1748,7 +1765,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
             c.alpha = inv_nk;
             c.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
+          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
         } else {  // ResBlock2.forward, models.py:136-141
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
@@ -1757,7 +1774,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
             a.alpha = inv_nk;
             a.accum = j > 0;
           }
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles));
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
         }
         rin = dst;
       }
@@ -1784,7 +1801,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     set_inputs(a);
     a.in_slope = 0.01f;
     a.out_act = ACT_TANH;
-    CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO));
+    CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO, nullptr, 1024, voc_host_len));
   }
   if (denoise) {  // HiFiGanVocoder.denoise (larynx/hifi_gan.py:171-179)
     ProfScope ps(ctx, w, KC_SMALL, 0);

@@ -27,8 +27,9 @@ struct PairArgs {
   float* y;        // output, same geometry (must not alias x)
   long long bs;
   int ld;
-  const int* len;  // valid length of row b = len[b] * len_mul
+  const int* len;  // valid length of row b = len ? len[b] * len_mul : len_const
   int len_mul;
+  int len_const;
   const float* w1;  // packed like conv_mfma's weights: [m-tile][octet][tap][64][4]
   const float* b1;
   const float* w2;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
   const int col = lane & 31, half = lane >> 5;
   const int rbase = 4 * half;
   const int b = blockIdx.z;
-  const int L = a.len[b] * a.len_mul;
+  const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
   int tile_x, tile_y;
   xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
   const int j0 = tile_x * T2;  // first output column of this workgroup
