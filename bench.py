@@ -106,6 +106,9 @@ def main():
                     help="utterances in flight per GPU in the timed region (host threads, each batch-1 call on its own "
                          "HIP streams — the reference's ThreadPoolExecutor pattern); the single-stream latency is "
                          "measured and reported next to it")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="utterances per call (rows of one padded batch). Default 1 = BASELINE.json's quoted configuration; "
+                         ">1 measures the micro-batched serving mode (a step is then one batch of this many utterances)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-branches", action="store_true",
                     help="also run the headline pass with the MRF chains on one stream (for rocprofv3 kernel traces)")
@@ -154,22 +157,23 @@ def main():
 
     # ---- synthetic utterances (one per step per rank), resident in HBM
     rng = np.random.default_rng(1234 + rank)
-    n_utts = args.steps + args.warmup
-    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(n_utts)])
+    n_utts = args.steps + args.warmup  # steps; each step is one call over `batch` utterances
+    B = max(1, args.batch)
+    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(n_utts * B)])
     ids_dev = torch.from_numpy(ids_host).to(dev)
-    lens = np.array([args.ids], np.int32)
+    lens = np.full(B, args.ids, np.int32)
     hop = vhp.hop
     max_samples = args.ids * 12 * hop
     conc = max(1, args.concurrency)
-    wav_f32 = [torch.empty(max_samples, dtype=torch.float32, device=dev) for _ in range(conc)]
-    wav_i16 = [torch.empty(max_samples, dtype=torch.int16, device=dev) for _ in range(conc)]
+    wav_f32 = [torch.empty(B * max_samples, dtype=torch.float32, device=dev) for _ in range(conc)]
+    wav_i16 = [torch.empty(B * max_samples, dtype=torch.int16, device=dev) for _ in range(conc)]
     s = ljspeech_audio_settings()
 
     def step(i, slot=0):
-        mel = eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, args.length_scale, None, 0, seed=1234 + i,
+        mel = eng.glow_infer_raw(g, ids_dev[i * B].data_ptr(), lens, args.ids, 0.667, args.length_scale, None, 0, seed=1234 + i,
                                  audio_settings=s, flags=ffi.IN_DEVICE)
         eng.hifigan_infer_raw(v, mel, wav_f32[slot].data_ptr(), wav_i16[slot].data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
-        f = int(mel.frames[0])
+        f = int(np.sum(mel.frames))
         mel.free()
         return f
 
@@ -253,8 +257,8 @@ def main():
     if rank == 0:
         K = args.steps
         audio_s = total_frames * hop / SAMPLE_RATE
-        utt_s = world * K / dt_clean
-        fpu = total_frames / (world * K)
+        utt_s = world * K * B / dt_clean
+        fpu = total_frames / (world * K * B)
         traffic = None
         tpath = REPO / "profiles" / "r01_roofline_traffic.json"
         if tpath.is_file():  # PMC counters cannot be read from inside this process: committed rocprofv3 passes
@@ -276,20 +280,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"en-us ljspeech GlowTTS + hifi_gan '{args.quality}', batch=1, {args.ids} phoneme ids per utterance "
+                "workload": f"en-us ljspeech GlowTTS + hifi_gan '{args.quality}', batch={B}, {args.ids} phoneme ids per utterance "
                             f"(~{fpu:.0f} frames = {fpu * hop / SAMPLE_RATE:.2f} s audio), seeded random weights, device RNG noise",
                 "ids_per_utterance": args.ids,
                 "length_scale": args.length_scale,
                 "frames_per_utterance": fpu,
                 "parallelism": f"utterance-dp{world}",
-                "utterances_in_flight_per_gpu": conc,
+                "batch": B,
+                "calls_in_flight_per_gpu": conc,
             },
             "rtf": dt_clean * world / audio_s,
             "x_realtime_per_gpu": audio_s / (dt_clean * world),
-            "latency_ms_single_stream": 1e3 * dt_latency / K,
+            "latency_ms_single_stream": 1e3 * dt_latency / K,  # per call (= per utterance at batch 1)
             "rtf_single_stream": dt_latency * world / audio_s,
             "x_realtime_single_stream": audio_s / (dt_latency * world),
-            "end_to_end_tflops_per_gpu": algorithmic_flop(args.ids, fpu, args.quality) * K / dt_clean / 1e12,
+            "end_to_end_tflops_per_gpu": algorithmic_flop(args.ids, fpu, args.quality) * K * B / dt_clean / 1e12,
             "roofline": {
                 "kernel": "HiFi-GAN ResBlock launches: conv_mfma_kernel (wide stages) + resblock_pair_kernel (32/64-channel stages)",
                 "bound": "mfma",

@@ -66,18 +66,32 @@ def load_models_broadcast(engine, glow_hp, voc_hp, glow_sd=None, voc_sd=None, de
     return g, v
 
 
+def micro_batches(indices: typing.Sequence[int], lengths: typing.Sequence[int], batch: int) -> typing.List[typing.List[int]]:
+    """Length-bucketed micro-batches: sort this rank's utterances by
+    id count and cut runs of `batch`, so the rows of one padded batch have similar
+    lengths and little of the launch is padding."""
+    order = sorted(indices, key=lambda i: (lengths[i], i))
+    return [order[k : k + batch] for k in range(0, len(order), max(1, batch))]
+
+
 def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[np.ndarray], rank: int, world: int,
                      noise_scale: float = 0.667, length_scale: float = 1.0, seed: int = 0, audio_settings=None,
-                     ) -> typing.Dict[int, np.ndarray]:
-    """This rank's share of the work list -> {utterance index: int16 audio}."""
-    mine = lpt_assign([len(r) for r in id_rows], world)[rank]
+                     batch: int = 1) -> typing.Dict[int, np.ndarray]:
+    """This rank's share of the work list -> {utterance index: int16 audio}.
+    `batch` > 1 runs length-bucketed micro-batches through one pair of calls each
+    (every row still equals its own batch-1 result: the kernels mask by row length)."""
+    lengths = [len(r) for r in id_rows]
+    mine = lpt_assign(lengths, world)[rank]
     out: typing.Dict[int, np.ndarray] = {}
     hop = engine.hop(vocoder)
-    for i in mine:
-        mel = engine.glow_infer(glow, np.asarray(id_rows[i], np.int64), noise_scale, length_scale, seed=seed + i,
-                                audio_settings=audio_settings)
+    for group in micro_batches(mine, lengths, batch):
+        rows = [np.asarray(id_rows[i], np.int64) for i in group]
+        # device RNG streams are keyed by (seed, row, channel, frame): give each call its own seed
+        mel = engine.glow_infer(glow, rows if len(rows) > 1 else rows[0], noise_scale, length_scale,
+                                seed=seed + group[0], audio_settings=audio_settings)
         _, i16 = engine.hifigan_infer(vocoder, mel, want_float=False)
-        out[i] = i16[0, : int(mel.frames[0]) * hop].copy()
+        for b, i in enumerate(group):
+            out[i] = i16[b, : int(mel.frames[b]) * hop].copy()
         mel.free()
     return out
 

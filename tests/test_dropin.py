@@ -75,6 +75,48 @@ def test_phonemes_to_speech_keeps_submission_order(emu_library, voice_dirs):
         assert np.array_equal(one, r.audio)
 
 
+def test_raw_stream_writes_sentences_in_order(emu_library, voice_dirs):
+    import io
+
+    from larynx_amd.streaming import stream_raw_pcm
+
+    gdir, vdir, *_ = voice_dirs
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, library_path=emu_library)
+    setattr(tts, "audio_settings", ljspeech_audio_settings())
+    rng = np.random.default_rng(11)
+    sents = [(f"s{i}", synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols), 0, 5 * (i % 2))
+             for i, n in enumerate((14, 5, 9, 7, 11, 6, 8))]
+    sink = io.BytesIO()
+    stats = stream_raw_pcm(iter(sents), tts, voc, sink, tts_settings={"noise_scale": 0.0}, max_thread_workers=2,
+                           raw_stream_queue_size=2, max_pending=3)
+    want = []
+    for _, ids, before, after in sents:
+        a = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
+        want.append(np.pad(a, (0, (after * 22050) // 1000)))
+    want = np.concatenate(want)
+    got = np.frombuffer(sink.getvalue(), np.int16)
+    assert stats.sentences == len(sents) and stats.samples == want.shape[0] == got.shape[0]
+    assert np.array_equal(got, want)
+    assert 0.0 < stats.seconds_to_first_audio <= stats.seconds_total
+
+    class Broken(io.BytesIO):
+        def write(self, b):
+            raise BrokenPipeError("sink closed")
+
+    with pytest.raises(BrokenPipeError):
+        stream_raw_pcm(iter(sents), tts, voc, Broken(), tts_settings={"noise_scale": 0.0})
+
+    def bad_source():
+        yield sents[0]
+        yield ("bad", [10 ** 6])  # id outside the symbol table: the task fails, the error surfaces here
+
+    from larynx_amd.ffi import Mi355ttsError
+
+    with pytest.raises(Mi355ttsError):
+        stream_raw_pcm(bad_source(), tts, voc, io.BytesIO(), tts_settings={"noise_scale": 0.0})
+
+
 def test_unsupported_requests_raise(emu_library, voice_dirs):
     gdir, vdir, *_ = voice_dirs
     with pytest.raises(ValueError):

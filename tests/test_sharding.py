@@ -23,6 +23,31 @@ def test_lpt_assign_balances_and_is_deterministic():
     assert lpt_assign(costs, 1) == [list(range(8))]
 
 
+def test_micro_batches_bucket_by_length():
+    from larynx_amd.sharding import micro_batches
+
+    lengths = [50, 10, 30, 12, 48, 31]
+    groups = micro_batches([0, 1, 2, 3, 4, 5], lengths, 2)
+    assert groups == [[1, 3], [2, 5], [4, 0]]
+    assert micro_batches([4, 2], lengths, 8) == [[2, 4]]
+
+
+def test_micro_batched_shard_equals_single_calls(emu_engine):
+    from larynx_amd import hparams as HP
+    from larynx_amd import sharding, synthetic
+
+    g = emu_engine.load_glow(HP.TINY_GLOW, synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7))
+    v = emu_engine.load_hifigan(HP.TINY_HIFIGAN, synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7))
+    rng = np.random.default_rng(1)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols) for n in (7, 15, 9, 12, 6)]
+    one = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.0)
+    many = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.0, batch=3)
+    assert sorted(one) == sorted(many) == list(range(5))
+    for i in range(5):
+        assert one[i].shape == many[i].shape
+        assert np.abs(one[i].astype(np.int32) - many[i].astype(np.int32)).max() <= 1
+
+
 def _worker(rank, world, port, lib, out_dir):
     sys.path.insert(0, str(REPO))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
