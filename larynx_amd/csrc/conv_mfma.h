@@ -20,6 +20,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef MI355TTS_ARING
+#define MI355TTS_ARING 3  // depth of the A-fragment register ring (steps in flight + 1)
+#endif
+
 namespace mi355tts {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -119,7 +123,11 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   constexpr int OCTS = CI_C / 8;     // octets per staged chunk
   constexpr int NO = OCTS / KS;      // octets per chunk per k-group
   constexpr int S = NO * K;          // MFMA k-steps per chunk per k-group
-  constexpr int RED = (KS - 1) * WN * NB * 16 * 64;
+  // the k-group reduction reuses the staging buffers as scratch; the reduce-scatter form
+  // (LINEAR / GATE) may go NBR column blocks per round to bound it
+  constexpr bool SCATTER = (EPI == EPI_LINEAR || EPI == EPI_GATE);
+  constexpr int NBR = (SCATTER && NB > 2) ? 1 : NB;
+  constexpr int RED = (KS - 1) * WN * NBR * 16 * 64;
   constexpr int XS = 2 * CI_C * XW;
   constexpr int LDSF = XS > RED ? XS : RED;
   static_assert(CI_C % 8 == 0 && CI_C % NWAVES == 0 && OCTS % KS == 0, "bad tile parameters");
@@ -251,19 +259,16 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   for (int mb = 0; mb < MB; ++mb)
     wq[mb] = reinterpret_cast<const float4*>(a.w) + (long long)(mt0 + mb) * a.noct * K * 64 + lane;
   const int last_chunk = nchunks - 1;
+  const int last_step = nchunks * S - 1;
   auto a_index = [&](int chunk, int q) -> long long {
-    // q may run past this chunk (prefetch): roll into the next one, clamp at the end
-    if (q >= S) {
-      if (chunk < last_chunk) {
-        chunk += 1;
-        q -= S;
-      } else {
-        q = S - 1;
-      }
-    }
+    // q may run past this chunk (prefetch): roll into the following ones, clamp at the end
+    int g = chunk * S + q;
+    g = g < last_step ? g : last_step;
+    const int ch = g / S;
+    q = g - ch * S;
     const int oi = q / K;
     const int k = q - oi * K;
-    return (long long)(((chunk * OCTS + kg + oi * KS) * K + k)) * 64;
+    return (long long)(((ch * OCTS + kg + oi * KS) * K + k)) * 64;
   };
 
   gload(0, preA);
@@ -271,14 +276,14 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   lstore(0, preA);
   __syncthreads();
 
-  // 3-deep register ring of A fragments: step q uses ar[q % 3] while the loads
-  // for steps q+1 and q+2 are in flight (L2 latency ~ one MFMA step)
-  float4 ar[3][MB];
+  // RD-deep register ring of A fragments: step q uses ar[q % RD] while the loads
+  // for steps q+1 .. q+RD-1 are in flight (L2 latency ~ one MFMA step)
+  constexpr int RD = MI355TTS_ARING;
+  float4 ar[RD][MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    ar[0][mb] = wq[mb][a_index(0, 0)];
-    ar[1][mb] = wq[mb][a_index(0, 1)];
-  }
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i) ar[i][mb] = wq[mb][a_index(0, i)];
 
   const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31) + (PA - a.pad);
 
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       // issue the loads for later steps first, then this step's MFMAs
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
-        if (!(a.ablate & 2)) ar[(s + 2) % 3][mb] = wq[mb][a_index(chunk, s + 2)];
+        if (!(a.ablate & 2)) ar[(s + RD - 1) % RD][mb] = wq[mb][a_index(chunk, s + RD - 1)];
       if (s + 1 < S) {
         const int oi = (s + 1) / K;
         const int k = (s + 1) - oi * K;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const float4 af = ar[s % 3][mb];
+          const float4 af = ar[s % RD][mb];
           const float av = (j == 0) ? af.x : (j == 1) ? af.y : (j == 2) ? af.z : af.w;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
@@ -326,19 +331,17 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
           for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = bnxt[j][nb];
       }
     }
-    // re-base the ring for the next chunk: its steps 0,1 sit in slots S%3, (S+1)%3
-    {
-      float4 r0[MB], r1[MB];
+    // re-base the ring for the next chunk: its steps 0..RD-2 sit in slots (S+i) % RD
+    if constexpr (S % RD != 0) {
+      float4 rr[RD - 1][MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        r0[mb] = ar[S % 3][mb];
-        r1[mb] = ar[(S + 1) % 3][mb];
-      }
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        ar[0][mb] = r0[mb];
-        ar[1][mb] = r1[mb];
-      }
+        for (int i = 0; i < RD - 1; ++i) rr[i][mb] = ar[(S + i) % RD][mb];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < RD - 1; ++i) ar[i][mb] = rr[i][mb];
     }
     if (more && !(a.ablate & 1)) lstore(buf ^ 1, pre_store);
     if (!(a.ablate & 4)) __syncthreads();
@@ -348,10 +351,67 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     if (chunk + 1 < nchunks) do_chunk(chunk + 1, preB, preA);
   }
 
-  if constexpr (KS > 1) {
-    // sum the k-groups' partial tiles through LDS, one m-block per round (the
-    // staging buffers are free: the loop ended on a barrier); group 0 then owns
-    // the epilogue
+  // ---------------------------------------------------------------- k-group reduction
+  // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  constexpr int R = 16 / KS;  // accumulator registers per 32x32 block that one k-group ends up owning
+  // Register g-th group owns (rr = 0..R-1).  LINEAR: R consecutive registers.  GATE pairs
+  // block rows i and i+16 = registers r and r+8 of one lane, so a group owns R/2 low
+  // registers and their partners.
+  auto reg_of = [](int g, int rr) constexpr -> int {
+    if constexpr (EPI == EPI_GATE) return rr < R / 2 ? g * (R / 2) + rr : 8 + g * (R / 2) + (rr - R / 2);
+    else return g * R + rr;
+  };
+  float own[MB][NB][R];
+  if constexpr (SCATTER) {
+    // Reduce-scatter: the KS partial tiles are summed through LDS so that EVERY k-group
+    // ends up with the finished values of 1/KS of the registers, and all WN x KS waves
+    // share the epilogue's loads and stores (a reduce-to-group-0 leaves KS-1 of every KS
+    // waves idle through the longest memory round trips of the kernel).  The staging
+    // buffers are free: the loop ended on a barrier.
+#pragma unroll
+    for (int g = 0; g < KS; ++g)
+      if (kg == g) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) own[mb][nb][rr] = acc[mb][nb][reg_of(g, rr)];
+      }
+    if constexpr (KS > 1) {
+      // scratch per round: owners x sources x WN x NBR blocks x R registers x 64 lanes
+      static_assert(NB % NBR == 0 && RED <= LDSF, "reduction scratch must fit in the staging buffers");
+      float* red = xs;
+      bool first_round = true;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb0 = 0; nb0 < NB; nb0 += NBR) {
+          if (!first_round) __syncthreads();
+          first_round = false;
+#pragma unroll
+          for (int g = 0; g < KS; ++g)
+            if (kg != g) {
+              const int si = kg < g ? kg : kg - 1;
+#pragma unroll
+              for (int nbi = 0; nbi < NBR; ++nbi)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                  red[((((g * (KS - 1) + si) * WN + wn) * NBR + nbi) * R + rr) * 64 + lane] = acc[mb][nb0 + nbi][reg_of(g, rr)];
+            }
+          __syncthreads();
+#pragma unroll
+          for (int si = 0; si < KS - 1; ++si)
+#pragma unroll
+            for (int nbi = 0; nbi < NBR; ++nbi)
+#pragma unroll
+              for (int rr = 0; rr < R; ++rr)
+                own[mb][nb0 + nbi][rr] += red[((((kg * (KS - 1) + si) * WN + wn) * NBR + nbi) * R + rr) * 64 + lane];
+        }
+    }
+  } else if constexpr (KS > 1) {
+    // sum the k-groups' partial tiles through LDS, one m-block per round; group 0 then
+    // owns the epilogue (COUPLING / UPSAMPLE: their epilogues need whole register sets)
     float* red = xs;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -378,8 +438,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   }
 
   // ---------------------------------------------------------------- epilogue
-  // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  // Loads (bias / residual / accumulate) go out in batches of 16 from clamped,
+  // Loads (bias / residual / accumulate) go out in batches from clamped,
   // always-valid addresses under wave-uniform conditions only; lanes outside the
   // tensor just skip the store.  (One exec-masked branch per element would cost a
   // full memory round trip per element.)
@@ -387,10 +446,17 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int rbase = 4 * (lane >> 5);
 
   if constexpr (EPI == EPI_LINEAR) {
+    // this wave finishes registers reg_of(kg, 0..R-1) of each of its blocks
+    int rowin[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int r = kg * R + rr;
+      rowin[rr] = (r & 3) + 8 * (r >> 2) + rbase;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int row0 = (mt0 + mb) * 32 + rbase;
-      const bool first = (mt0 + mb) * 32 < a.split;  // split is a multiple of 32 (or 0 / >= rows)
+      const int row0 = (mt0 + mb) * 32;
+      const bool first = row0 < a.split;  // split is a multiple of 32 (or 0 / >= rows)
       float* yp = first ? a.y : a.y2;
       const long long ybs = first ? a.y_bs : a.y2_bs;
       const int yld = first ? a.y_ld : a.y2_ld;
@@ -399,59 +465,108 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       const bool acc_on = first ? (a.accum != 0) : (a.accum2 != 0);
       const float alpha = first ? a.alpha : 1.0f;
       const int act = first ? a.out_act : (int)ACT_NONE;
-      float bb[16];
+      float bb[R];
+      int roff[R];
+      bool rok[R];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        bb[r] = a.bias ? a.bias[row] : 0.f;  // packed bias is padded to whole m-tiles
+      for (int rr = 0; rr < R; ++rr) {
+        const int row = row0 + rowin[rr];
+        bb[rr] = a.bias ? a.bias[row] : 0.f;  // packed bias is padded to whole m-tiles
+        rok[rr] = row < a.rows;
+        roff[rr] = ((rok[rr] ? row : a.rows - 1) - rowoff) * yld;
       }
+      float v[NB][R];
+      int tcol[NB];
+      bool tok[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int t = t0 + (wn * NB + nb) * 32 + col;
-        const bool tok = t < Lout;
-        const int tc = tok ? t : Lout - 1;
-        float* yb = yp + (long long)b * ybs + tc;
-        const float* rb = rp ? rp + (long long)b * ybs + tc : nullptr;
-        int off[16];
-        bool ok[16];
-        float v[16];
+        tok[nb] = t < Lout;
+        tcol[nb] = tok[nb] ? t : Lout - 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (r & 3) + 8 * (r >> 2);
-          const bool rok = row < a.rows;
-          ok[r] = rok && tok;
-          off[r] = ((rok ? row : a.rows - 1) - rowoff) * yld;
-          v[r] = acc[mb][nb][r] + bb[r];
-        }
-        if (rb) {
-          float rv[16];
+        for (int rr = 0; rr < R; ++rr) v[nb][rr] = own[mb][nb][rr] + bb[rr];
+      }
+      float* yb = yp + (long long)b * ybs;
+      if (rp) {
+        const float* rb = rp + (long long)b * ybs;
+        float rv[NB][R];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = rb[off[r]];
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += rv[r];
-        }
+          for (int rr = 0; rr < R; ++rr) rv[nb][rr] = rb[roff[rr] + tcol[nb]];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] *= alpha;
-        if (acc_on) {
-          float ov[16];
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ov[r] = yb[off[r]];
+          for (int rr = 0; rr < R; ++rr) v[nb][rr] += rv[nb][rr];
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += ov[r];
-        }
-        if (act == ACT_RELU) {
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        } else if (act == ACT_TANH) {
+        for (int rr = 0; rr < R; ++rr) v[nb][rr] *= alpha;
+      if (acc_on) {
+        float ov[NB][R];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
-        }
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ok[r]) yb[off[r]] = v[r];
+          for (int rr = 0; rr < R; ++rr) ov[nb][rr] = yb[roff[rr] + tcol[nb]];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) v[nb][rr] += ov[nb][rr];
+      }
+      if (act == ACT_RELU) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) v[nb][rr] = v[nb][rr] > 0.f ? v[nb][rr] : 0.f;
+      } else if (act == ACT_TANH) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) v[nb][rr] = tanhf(v[nb][rr]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+          if (rok[rr] && tok[nb]) yb[roff[rr] + tcol[nb]] = v[nb][rr];
+    }
+  } else if constexpr (EPI == EPI_GATE) {
+    static_assert(MB == 1, "paired epilogues use one 32-row tile: 16 rows of each half");
+    // virtual tile p = blockIdx.y holds rows c = 16p + i (i < 16) of the first half
+    // (tanh) in block rows 0..15 and the matching rows of the second half (sigmoid) in
+    // block rows 16..31.  In the C/D map, block row i and row i + 16 sit in the SAME
+    // lane, registers r and r + 8 — the pair meets in registers; this wave owns the low
+    // registers kg*H .. kg*H+H-1 and their partners (own[..][H + rr]).
+    constexpr int H = R / 2;
+    static_assert(H >= 1, "GATE needs at most 8 k-groups");
+    float b0[H], b1[H];
+    int off[H];
+    bool cok[H];
+#pragma unroll
+    for (int rr = 0; rr < H; ++rr) {
+      const int r = kg * H + rr;
+      const int i = (r & 3) + 8 * (r >> 2) + rbase;  // 0..15
+      b0[rr] = a.bias ? a.bias[mt0 * 32 + i] : 0.f;
+      b1[rr] = a.bias ? a.bias[mt0 * 32 + 16 + i] : 0.f;
+      const int c = tile_y * 16 + i;
+      cok[rr] = c < a.half;
+      off[rr] = (cok[rr] ? c : a.half - 1) * a.y_ld;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int t = t0 + (wn * NB + nb) * 32 + col;
+      const bool tok = t < Lout;
+      float* yb = a.y + (long long)b * a.y_bs + (tok ? t : Lout - 1);
+#pragma unroll
+      for (int rr = 0; rr < H; ++rr) {
+        const float v0 = own[0][nb][rr] + b0[rr];
+        const float v1 = own[0][nb][H + rr] + b1[rr];
+        const float out = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
+        if (cok[rr] && tok) yb[off[rr]] = out;
       }
     }
-  } else if constexpr (EPI == EPI_GATE || EPI == EPI_COUPLING) {
+  } else if constexpr (EPI == EPI_COUPLING) {
     static_assert(MB == 1, "paired epilogues use one 32-row tile: 16 rows of each half");
     // virtual tile p = blockIdx.y holds rows c = 16p + i (i < 16) of the first half
     // (tanh / m) in block rows 0..15 and the matching rows of the second half
@@ -480,14 +595,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
         off[r] = (cok ? c : a.half - 1) * a.y_ld;
       }
       float out[8];
-      if constexpr (EPI == EPI_GATE) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const float v0 = acc[0][nb][r] + b0[r];
-          const float v1 = acc[0][nb][r + 8] + b1[r];
-          out[r] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
-        }
-      } else {
+      {
         const float* rb = a.res + (long long)b * a.y_bs + tc;
         float rv[8];
 #pragma unroll

@@ -482,8 +482,9 @@ template <> struct ConvCfg<7> { static constexpr int HALO = 76; };
 template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 
 // Tile shapes (all 512 threads):
-// (2-column-block-per-wave variants at 64/128 columns and a 256-thread variant without
-//  k-split were measured in round 1 and never won; see profiles/r01_conv_sweep.txt)
+// (2-column-block-per-wave variants at 64/128 columns, a 256-thread variant without
+//  k-split, and one-m-tile "wide" tiles with 2 or 4 column blocks per wave were measured
+//  in round 1 and did not win overall; see profiles/r01_conv_sweep*.txt)
 //   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
 //   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
 //   NB1   : 4 time-waves x 2 k-groups, 128 columns

@@ -9,7 +9,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from larynx_amd.engine import Engine  # noqa: E402
 
-eng = Engine(0)
+eng = Engine(0, library_path=os.environ.get("MI355TTS_LIB"))  # experiments: an alternative build
 cases = [(128, 128, 11, 1, 39936, 0), (128, 128, 11, 1, 399360, 1), (128, 128, 11, 1, 399360, 2),
          (128, 128, 3, 1, 399360, 1), (32, 32, 3, 1, 1597440, 1), (256, 256, 11, 1, 4992, 3)]
 masks = [int(m) for m in os.environ.get("PROBE_MASKS", "0,1,2,4,7").split(",")]

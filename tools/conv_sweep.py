@@ -2,6 +2,7 @@
 """Per-layer micro-benchmark of conv_mfma_kernel on the HiFi-GAN 'high' ResBlock
 geometries of the standard utterance (F = 624), every tile shape.
 Run on the GPU box:  python tools/conv_sweep.py [frames]"""
+import os
 import sys
 from pathlib import Path
 
@@ -9,8 +10,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from larynx_amd.engine import Engine  # noqa: E402
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 624
-eng = Engine(0)
-SHAPES = (3, 0, 1, 2)
+eng = Engine(0, library_path=os.environ.get("MI355TTS_LIB"))  # experiments: an alternative build
+SHAPES = tuple(int(t) for t in os.environ.get("SWEEP_SHAPES", "3,0,1,2").split(","))
 layers = []
 for stage, (C, mul) in enumerate([(256, 8), (128, 64), (64, 128), (32, 256)]):
     for K in (3, 7, 11):
