@@ -1660,7 +1660,9 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   }
   // concurrent chains share the chip: 300 tiles per launch measured best (sweeps of 80..1024,
   // also per-chain values, in round 1: 6.6 ms vs 7.05 ms per utterance at 1024)
-  const int rb_tiles = concurrent ? 300 : 1024;
+  // tuning knob: MI355TTS_RB_TILES overrides the per-chain workgroup target of the concurrent schedule
+  static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
+  const int rb_tiles = concurrent ? (rb_env > 0 ? rb_env : 300) : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
   const int nbuf = concurrent ? 2 + 4 * nk : 6;
   Carver cv;
