@@ -35,6 +35,12 @@ def build_emu() -> Path:
         f"-I{HERE / 'include'}", *map(str, srcs), "-o", str(out), "-lpthread",
     ]
     subprocess.run(cmd, check=True, cwd=str(REPO))
+    for old in OUT_DIR.glob("libmi355tts_emu_*.so"):  # builds of earlier source states
+        if old != out:
+            try:
+                old.unlink()
+            except OSError:
+                pass
     return out
 
 

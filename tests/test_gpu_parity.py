@@ -62,6 +62,24 @@ def test_conv1d_every_tile_shape(gpu_engine, monkeypatch, shape, Cin, Cout, K, d
     np.testing.assert_allclose(y[0], ref, rtol=1e-4, atol=5e-5)
 
 
+def test_conv1d_random_shapes_full_size(gpu_engine):
+    """The emulator suite's randomised conv check (tests/test_emu_random.py) at real
+    channel counts and lengths, on the device."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    from tests.test_emu_random import TAPS, check_conv1d
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(taps=TAPS, cin=st.integers(1, 300), cout=st.integers(1, 300), L=st.integers(1, 6000), B=st.integers(1, 3),
+           shape=st.sampled_from([-1, 0, 1, 2, 3]), slope=st.sampled_from([1.0, 0.1]), act=st.sampled_from([0, 1, 2]),
+           seed=st.integers(0, 2 ** 16))
+    def run(taps, cin, cout, L, B, shape, slope, act, seed):
+        check_conv1d(gpu_engine, taps, cin, cout, L, B, shape, slope, act, seed)
+
+    run()
+
+
 @pytest.mark.parametrize("Cin,Cout,K,u,L", [(16, 8, 16, 8, 50), (512, 256, 16, 8, 624), (64, 32, 4, 2, 5000)])
 def test_conv_transpose1d_kernel(gpu_engine, Cin, Cout, K, u, L):
     rng = np.random.default_rng(K * 100 + u)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Soak test on one GPU: N host threads hammer one engine with random-length sentences on
+three resident voices and two vocoders, a share of the calls with the denoiser on; every
+result must be finite, of the expected length, identical when the whole job list is run a
+second time, and equal to a single-threaded recomputation for a sample.  VRAM use after
+pass 1 and pass 2 must match (leak check: workspaces are grow-only per worker).
+Run on the GPU box:  python tools/stress.py [--calls 1500] [--threads 4]"""
+import argparse
+import json
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from larynx_amd import hparams as HP  # noqa: E402
+from larynx_amd import synthetic  # noqa: E402
+from larynx_amd.audio import ljspeech_audio_settings  # noqa: E402
+from larynx_amd.engine import Engine  # noqa: E402
+
+
+def vram_used():
+    try:
+        out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--json"], capture_output=True, text=True, timeout=30).stdout
+        d = json.loads(out)
+        return int(next(iter(d.values()))["VRAM Total Used Memory (B)"])
+    except Exception:  # noqa: BLE001 - diagnostics only
+        return -1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calls", type=int, default=1500)
+    ap.add_argument("--threads", type=int, default=4)
+    args = ap.parse_args()
+    eng = Engine(0)
+    s = ljspeech_audio_settings()
+    vocs = [(hp, eng.load_hifigan(hp, synthetic.make_hifigan_state_dict(hp, seed=1234))) for hp in (HP.HIFIGAN_HIGH, HP.HIFIGAN_LOW)]
+    voices = [(hp, eng.load_glow(hp, synthetic.make_glow_state_dict(hp, seed=1234))) for hp in (HP.LJSPEECH, HP.THORSTEN, HP.SIWIS)]
+    rng = np.random.default_rng(99)
+    jobs = []
+    for i in range(args.calls):
+        ghp, g = voices[int(rng.integers(3))]
+        vhp, v = vocs[int(rng.integers(2))]
+        B = 1 if rng.random() < 0.8 else int(rng.integers(2, 5))
+        rows = [synthetic.synthetic_phoneme_ids(rng, int(rng.integers(1, 220)), ghp.num_symbols) for _ in range(B)]
+        jobs.append((i, g, v, vhp, rows, 0.01 if rng.random() < 0.2 else 0.0))
+
+    def run(job):
+        i, g, v, vhp, rows, dn = job
+        mel = eng.glow_infer(g, rows if len(rows) > 1 else rows[0], 0.667, 0.8, seed=i, audio_settings=s)
+        frames = [int(f) for f in mel.frames]
+        if dn > 0 and min(frames) * vhp.hop <= 1024:
+            dn = 0.0  # shorter than one STFT frame: the reference raises, so does the library
+        wav, i16 = eng.hifigan_infer(v, mel, denoiser_strength=dn)
+        mel.free()
+        assert np.isfinite(wav).all()
+        for b, f in enumerate(frames):
+            n = f * vhp.hop
+            assert np.all(i16[b, n:] == 0)
+            assert dn > 0 or np.abs(wav[b, :n]).max() > 0
+        return i, frames, i16
+
+    used0 = vram_used()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(args.threads) as pool:
+        results = list(pool.map(run, jobs))
+        dt = time.perf_counter() - t0
+        used1 = vram_used()  # models + grow-only per-worker workspaces sized for the largest call seen
+        # same work again, several times: results identical; the workspaces are grow-only per
+        # worker, so VRAM use may still rise while a worker meets its first largest call, and
+        # must then stay flat
+        trail = [used1]
+        for _ in range(4):
+            again = list(pool.map(run, jobs))
+            trail.append(vram_used())
+            for a, b in zip(results, again):
+                assert a[1] == b[1] and np.array_equal(a[2], b[2])
+    used2 = trail[-1]
+    # determinism under concurrency: recompute a sample single-threaded
+    for k in range(0, len(jobs), max(1, len(jobs) // 25)):
+        i, frames, i16 = run(jobs[k])
+        assert frames == results[k][1] and np.array_equal(i16, results[k][2]), f"job {k} differs when recomputed"
+    for _, g in voices:
+        eng.unload(g)
+    for _, v in vocs:
+        eng.unload(v)
+    eng.close()
+    print(json.dumps({"calls": args.calls, "threads": args.threads, "seconds": dt, "calls_per_s": args.calls / dt,
+                      "vram_used_before": used0, "vram_used_after_each_pass": trail,
+                      "growth_last_pass_bytes": trail[-1] - trail[-2]}))
+
+
+if __name__ == "__main__":
+    main()
