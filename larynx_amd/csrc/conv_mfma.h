@@ -20,6 +20,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Micro-benchmark ablations (tools/conv_probe.py) are compiled in only for probe builds
+// (-DMI355TTS_ABLATION): a runtime test around the weight loads puts them behind a branch,
+// and the compiler's s_waitcnt insertion must then assume either path at every join — it
+// emitted vmcnt(0) drains inside the MFMA loop, which cost the product kernel ~10 %.
+#ifdef MI355TTS_ABLATION
+#define MI355TTS_ABLATE(a, bit) ((a).ablate & (bit))
+#else
+#define MI355TTS_ABLATE(a, bit) 0
+#endif
+
 #ifndef MI355TTS_ARING
 #define MI355TTS_ARING 3  // depth of the A-fragment register ring (steps in flight + 1)
 #endif
@@ -87,9 +97,9 @@ struct ConvArgs {
   const float* mix_w;      // [4][4] inverse weight
   const float* mix_bias;   // [2*half] ActNorm bias
   const float* mix_scale;  // [2*half] exp(-logs)
-  // micro-benchmark ablations (tools/conv_probe.py; results are WRONG when set):
-  // bit0 = no activation staging after chunk 0, bit1 = no A-fragment loads after
-  // the prologue, bit2 = no per-chunk barrier
+  // micro-benchmark ablations, honoured only by -DMI355TTS_ABLATION builds
+  // (tools/conv_probe.py; results are WRONG when set): bit0 = no activation staging after
+  // chunk 0, bit1 = no A-fragment loads after the prologue, bit2 = no per-chunk barrier
   int ablate;
 };
 
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   auto do_chunk = [&](int chunk, float4 (&pre_load)[NE], const float4 (&pre_store)[NE]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
-    if (chunk + 2 < nchunks && !(a.ablate & 1)) gload(chunk + 2, pre_load);
+    if (chunk + 2 < nchunks && !MI355TTS_ABLATE(a, 1)) gload(chunk + 2, pre_load);
     const float* xt = xs + buf * (CI_C * XW) + b_off + kg * 8 * XW;
     float bcur[4][NB], bnxt[4][NB];
 #pragma unroll
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       // issue the loads for later steps first, then this step's MFMAs
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
-        if (!(a.ablate & 2)) ar[(s + RD - 1) % RD][mb] = wq[mb][a_index(chunk, s + RD - 1)];
+        if (!MI355TTS_ABLATE(a, 2)) ar[(s + RD - 1) % RD][mb] = wq[mb][a_index(chunk, s + RD - 1)];
       if (s + 1 < S) {
         const int oi = (s + 1) / K;
         const int k = (s + 1) - oi * K;
@@ -343,8 +353,8 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < RD - 1; ++i) ar[i][mb] = rr[i][mb];
     }
-    if (more && !(a.ablate & 1)) lstore(buf ^ 1, pre_store);
-    if (!(a.ablate & 4)) __syncthreads();
+    if (more && !MI355TTS_ABLATE(a, 1)) lstore(buf ^ 1, pre_store);
+    if (!MI355TTS_ABLATE(a, 4)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunks; chunk += 2) {
     do_chunk(chunk, preA, preB);

@@ -1,6 +1,11 @@
 #!/usr/bin/env python
 """Conv micro-benchmark probe: a few geometries x tile shapes x ablation masks
 (MI355TTS_BENCH_ABLATE: 1 = no activation staging, 2 = no weight loads, 4 = no barrier).
+The product library ignores the masks; build a probe library first and point MI355TTS_LIB at it:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMI355TTS_ABLATION \
+        larynx_amd/csrc/mi355tts.hip -o larynx_amd/lib_probe.so
+(the runtime tests the probe build adds around the weight loads cost it ~10 % on their own:
+compare its mask-0 column with the product library's).
 rocprofv3 --pmc ... -- python tools/conv_probe.py"""
 import os
 import sys
