@@ -751,6 +751,8 @@ static int check_glow_hp(const mi355tts_glow_hparams* h) {
   if (!h) return fail(MI355TTS_ERR_INVALID, "hparams null");
   if (h->num_symbols <= 0 || h->hidden_channels <= 0 || h->n_heads <= 0 || h->hidden_channels % h->n_heads)
     return fail(MI355TTS_ERR_INVALID, "bad GlowTTS hparams");
+  if (h->hidden_channels % 32)  // WaveNet res/skip rows are split on a 32-row tile boundary (all 51 shipped voices: 192)
+    return fail(MI355TTS_ERR_INVALID, "hidden_channels %d must be a multiple of 32", h->hidden_channels);
   if (h->hidden_channels / h->n_heads > ATT_MAXDK) return fail(MI355TTS_ERR_INVALID, "head dim > %d unsupported", ATT_MAXDK);
   if (2 * h->window_size + 1 > ATT_MAXW) return fail(MI355TTS_ERR_INVALID, "window_size too large");
   if (h->n_split > 8 || h->n_split % 2 || (h->mel_channels * h->n_sqz) % h->n_split)
