@@ -119,7 +119,8 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
 }
 
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
-__global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs a) {
+// (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
+__global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
   // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
   // (NB blocks of 32 columns each); the KS k-groups split the staged input
   // channels between them (octet o goes to group o % KS) and are summed through
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
   const int used4 = (PA - a.pad + roww + 3) >> 2;  // float4s per row actually needed
   const int cin_last = a.Cin - 1;
   const int ld_last4 = a.x_ld - 4;
+  // gload only ISSUES the loads of a chunk (raw values stay in flight in `pre`); the
+  // masking and the input activation are applied in lstore, one chunk of MFMA work later,
+  // when the data has long arrived.  (Doing them in gload made every wave wait for its
+  // own prefetch at the top of each chunk — a full memory round trip per chunk.)
   auto gload = [&](int chunk, float4 (&pre)[NE]) {
     int off[NE];
 #pragma unroll
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + off[i]);
-    if (xb2) {  // wave-uniform: MRF average of the previous stage's chains, batched
+    if (xb2) {  // wave-uniform: MRF average of the previous stage's chains, batched (this path waits)
       float4 t2[NE];
 #pragma unroll
       for (int i = 0; i < NE; ++i) t2[i] = *reinterpret_cast<const float4*>(xb2 + off[i]);
@@ -227,6 +232,9 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
         pre[i].w = pre[i].w / a.in_div;
       }
     }
+  };
+  auto lstore = [&](int buf, int chunk, const float4 (&pre)[NE]) {
+    float4* dst = reinterpret_cast<float4*>(xs + buf * (CI_C * XW));
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int e = tid + NT * i;
@@ -242,15 +250,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
       v.y = v.y > 0.f ? v.y : v.y * slope;
       v.z = v.z > 0.f ? v.z : v.z * slope;
       v.w = v.w > 0.f ? v.w : v.w * slope;
-      pre[i] = v;
-    }
-  };
-  auto lstore = [&](int buf, const float4 (&pre)[NE]) {
-    float4* dst = reinterpret_cast<float4*>(xs + buf * (CI_C * XW));
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + NT * i;
-      if (e < NF4) dst[e] = pre[i];  // rows are XW = 4*XW4 floats: the flat float4 index IS the LDS index
+      if (e < NF4) dst[e] = v;  // rows are XW = 4*XW4 floats: the flat float4 index IS the LDS index
     }
   };
 
@@ -281,19 +281,22 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
     return (long long)(((ch * OCTS + kg + oi * KS) * K + k)) * 64;
   };
 
-  gload(0, preA);
-  if (nchunks > 1) gload(1, preB);
-  lstore(0, preA);
-  __syncthreads();
-
   // RD-deep register ring of A fragments: step q uses ar[q % RD] while the loads
   // for steps q+1 .. q+RD-1 are in flight (L2 latency ~ one MFMA step)
   constexpr int RD = MI355TTS_ARING;
   float4 ar[RD][MB];
+
+  // prologue: everything the first MFMA needs goes out in ONE batch of loads — the
+  // first activation chunk, the first weight fragments (cold in L2: a layer's weights are
+  // read for the first time here), then the second chunk — before anything is waited for
+  gload(0, preA);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int i = 0; i < RD - 1; ++i) ar[i][mb] = wq[mb][a_index(0, i)];
+  if (nchunks > 1) gload(1, preB);
+  lstore(0, 0, preA);
+  __syncthreads();
 
   const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31) + (PA - a.pad);
 
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64 * WN * KS) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < RD - 1; ++i) ar[i][mb] = rr[i][mb];
     }
-    if (more && !MI355TTS_ABLATE(a, 1)) lstore(buf ^ 1, pre_store);
+    if (more && !MI355TTS_ABLATE(a, 1)) lstore(buf ^ 1, chunk + 1, pre_store);
     if (!MI355TTS_ABLATE(a, 4)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunks; chunk += 2) {
