@@ -135,7 +135,7 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    eng = Engine(device=local)
+    eng = Engine(device=local, library_path=os.environ.get("MI355TTS_LIB"))  # MI355TTS_LIB: A/B an alternative build
     ghp, vhp = HP.LJSPEECH, HP.VOCODER_QUALITY[args.quality]
     # ---- weights: rank 0 folds, everyone receives over RCCL/xGMI
     man_g = ffi.manifest(eng.lib, ffi.glow_hparams_c(ghp))
