@@ -59,3 +59,33 @@ def test_manifest_matches_reference_checkpoint_keys():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         ffi.load_library(tmp_path / "libmi355tts.so")
+
+
+def test_every_shipped_voice_and_vocoder_config_is_accepted():
+    """All 51 voice configs and the three vocoder configs of the reference
+    (tests/golden/reference_configs.json, made by oracle/make_config_fixture.py) parse into
+    hyper-parameters the library accepts: its manifest enumerates tensors for each."""
+    import json
+
+    from larynx_amd import hparams as HP
+    from larynx_amd.audio import AudioSettings
+
+    lib = ffi.load_library(build())
+    cfgs = json.loads((REPO / "tests" / "golden" / "reference_configs.json").read_text())
+    assert len(cfgs["voices"]) == 51 and set(cfgs["vocoders"]) == {"universal_large", "vctk_medium", "vctk_small"}
+    symbols = set()
+    for name, cfg in cfgs["voices"].items():
+        hp = HP.GlowHParams.from_config(cfg)
+        man = ffi.manifest(lib, ffi.glow_hparams_c(hp))
+        assert sum(n for _, n in man) > 20_000_000, name  # ~28.5 M parameters each
+        symbols.add(hp.num_symbols)
+        # the audio block feeds the fused mel transforms
+        known = {k: v for k, v in cfg["audio"].items() if k in AudioSettings.__dataclass_fields__}
+        ffi.audio_settings_c(AudioSettings(**known))
+    assert symbols == {38, 41, 42, 44, 46, 52, 54, 58}  # SURVEY.md: the vocabularies the voices use
+    params = {}
+    for name, cfg in cfgs["vocoders"].items():
+        hp = HP.HifiGanHParams.from_config(cfg)
+        params[name] = sum(n for _, n in ffi.manifest(lib, ffi.hifigan_hparams_c(hp)))
+    # parameter counts after weight-norm folding (SURVEY.md §8(a))
+    assert params == {"universal_large": 13_926_017, "vctk_medium": 925_985, "vctk_small": 1_462_273}
