@@ -62,6 +62,31 @@ def test_models_behave_like_the_reference_classes(emu_library, voice_dirs):
     np.testing.assert_allclose(np.asarray(mel)[0], ref_mel, atol=2e-5)
 
 
+def test_reference_pth_checkpoints_load(emu_library, voice_dirs, tmp_path):
+    """The reference's own checkpoint files: `generator.pth` = torch-pickled
+    `{"model": state_dict}` (glow_tts/checkpoint.py:41) / `{"generator": state_dict}`
+    (hifi_gan/checkpoint.py:49), read with `weights_only=True`."""
+    import shutil
+
+    import torch
+
+    gdir, vdir, gsd, vsd = voice_dirs
+    g2, v2 = tmp_path / "pth-glow_tts", tmp_path / "pth_hifi_gan"
+    g2.mkdir()
+    v2.mkdir()
+    shutil.copy(gdir / "config.json", g2 / "config.json")
+    shutil.copy(vdir / "config.json", v2 / "config.json")
+    torch.save({"model": {k: torch.from_numpy(np.asarray(v)) for k, v in gsd.items()}, "global_step": 1}, g2 / "generator.pth")
+    torch.save({"generator": {k: torch.from_numpy(np.asarray(v)) for k, v in vsd.items()}}, v2 / "generator.pth")
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(4), 11, HP.TINY_GLOW.num_symbols)
+    out = []
+    for gd, vd in ((gdir, vdir), (g2, v2)):
+        tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gd, library_path=emu_library)
+        voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vd, library_path=emu_library)
+        out.append(voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0})))
+    assert out[0].size > 0 and np.array_equal(out[0], out[1])
+
+
 def test_phonemes_to_speech_keeps_submission_order(emu_library, voice_dirs):
     gdir, vdir, gsd, vsd = voice_dirs
     tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
