@@ -181,7 +181,11 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
   constexpr int NF4 = CI_C * XW4;             // float4s per staged chunk
   constexpr int NE = (NF4 + NT - 1) / NT;     // per thread, flattened over (row, float4) so no lane idles
   static_assert(XW % 4 == 0, "LDS row stride must be a multiple of 4 floats");
-  float4 preA[NE], preB[NE];
+  // Prefetch distance: two chunks (two register sets) by default; the 64-row one-time-wave
+  // tiles with wide halos (k >= 7: 4 float4 per thread per chunk) prefetch one chunk ahead
+  // with a single set, which keeps them under 128 VGPRs (two workgroups per CU) unspilled.
+  constexpr bool PD1 = (WN == 1 && KS == 8 && MB == 2 && K >= 7);
+  float4 preA[NE], preB[PD1 ? 1 : NE];
   const int PA = (a.pad + 3) & ~3;
   const int used4 = (PA - a.pad + roww + 3) >> 2;  // float4s per row actually needed
   const int cin_last = a.Cin - 1;
@@ -294,7 +298,9 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int i = 0; i < RD - 1; ++i) ar[i][mb] = wq[mb][a_index(0, i)];
-  if (nchunks > 1) gload(1, preB);
+  if constexpr (!PD1) {
+    if (nchunks > 1) gload(1, preB);
+  }
   lstore(0, 0, preA);
   __syncthreads();
 
@@ -303,7 +309,11 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
   auto do_chunk = [&](int chunk, float4 (&pre_load)[NE], const float4 (&pre_store)[NE]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
-    if (chunk + 2 < nchunks && !MI355TTS_ABLATE(a, 1)) gload(chunk + 2, pre_load);
+    if constexpr (PD1) {
+      if (more) gload(chunk + 1, pre_load);
+    } else {
+      if (chunk + 2 < nchunks && !MI355TTS_ABLATE(a, 1)) gload(chunk + 2, pre_load);
+    }
     const float* xt = xs + buf * (CI_C * XW) + b_off + kg * 8 * XW;
     float bcur[4][NB], bnxt[4][NB];
 #pragma unroll
@@ -359,9 +369,13 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
     if (more && !MI355TTS_ABLATE(a, 1)) lstore(buf ^ 1, chunk + 1, pre_store);
     if (!MI355TTS_ABLATE(a, 4)) __syncthreads();
   };
-  for (int chunk = 0; chunk < nchunks; chunk += 2) {
-    do_chunk(chunk, preA, preB);
-    if (chunk + 1 < nchunks) do_chunk(chunk + 1, preB, preA);
+  if constexpr (PD1) {
+    for (int chunk = 0; chunk < nchunks; ++chunk) do_chunk(chunk, preA, preA);
+  } else {
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      do_chunk(chunk, preA, preB);
+      if (chunk + 1 < nchunks) do_chunk(chunk + 1, preB, preA);
+    }
   }
 
   // ---------------------------------------------------------------- k-group reduction
