@@ -73,11 +73,11 @@ def sentence_task(text: str, phoneme_ids, audio_settings, tts_model, tts_setting
     _LOGGER.debug("Got mels in %s second(s) (shape=%s, text='%s')", t1 - t0, getattr(mels, "shape", None), text)
     if audio_settings is not None and (audio_settings.signal_norm or audio_settings.convert_db_to_amp
                                        or audio_settings.do_dynamic_range_compression):
-        # a non-fused TextToSpeechModel: hand the transforms to the kernel path via the mel wrapper
+        # a non-fused TextToSpeechModel (e.g. the reference's own GlowTextToSpeech feeding the HIP
+        # vocoder): the three transforms still run in-kernel, applied while wrapping the array
         from .glow_tts import mels_as_numpy
-        from .runtime import get_engine
 
-        mels = get_engine(getattr(vocoder_model.engine, "device", 0)).mel_from_numpy(mels_as_numpy(mels), audio_settings=audio_settings)
+        mels = vocoder_model.engine.mel_from_numpy(mels_as_numpy(mels), audio_settings=audio_settings)
     t2 = time.perf_counter()
     audio = vocoder_model.mels_to_audio(mels, settings=vocoder_settings)
     t3 = time.perf_counter()

@@ -87,6 +87,31 @@ def test_reference_pth_checkpoints_load(emu_library, voice_dirs, tmp_path):
     assert out[0].size > 0 and np.array_equal(out[0], out[1])
 
 
+def test_reference_style_tts_model_feeds_the_hip_vocoder(emu_library, voice_dirs):
+    """Mixed deployment: a TextToSpeechModel that returns a plain `[1, M, F]` array with the
+    un-fused `audio_settings` (what the reference's own GlowTextToSpeech does) in front of
+    the HIP vocoder.  `sentence_task` then applies the three mel transforms in-kernel while
+    wrapping the array; the result equals the fully fused path."""
+    from larynx_amd.interfaces import TextToSpeechModel
+
+    gdir, vdir, *_ = voice_dirs
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, library_path=emu_library)
+    setattr(tts, "audio_settings", ljspeech_audio_settings())
+
+    class ArrayTTS(TextToSpeechModel):
+        def __init__(self):
+            pass
+
+        def phonemes_to_mels(self, phoneme_ids, settings=None):
+            return np.asarray(tts.phonemes_to_mels(phoneme_ids, settings))  # raw GlowTTS output, host array
+
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(6), 12, HP.TINY_GLOW.num_symbols)
+    fused = larynx_amd.sentence_task("x", ids, tts.audio_settings, tts, {"noise_scale": 0.0}, voc, None)
+    mixed = larynx_amd.sentence_task("x", ids, ljspeech_audio_settings(), ArrayTTS(), {"noise_scale": 0.0}, voc, None)
+    assert fused.shape == mixed.shape and np.array_equal(fused, mixed)
+
+
 def test_phonemes_to_speech_keeps_submission_order(emu_library, voice_dirs):
     gdir, vdir, gsd, vsd = voice_dirs
     tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
