@@ -138,6 +138,29 @@ def test_glow_multi_block_attention(emu_engine):
     emu_engine.unload(g)
 
 
+def check_fallback_kernels(engine):
+    """Hyper-parameters no shipped voice uses still take correct (slower) paths:
+    `n_split = 8` runs InvConvNear + ActNorm as the standalone kernel instead of inside the
+    coupling epilogue, a 264-channel duration predictor uses the generic LayerNorm, and an
+    input longer than the MFMA attention's score tile (768 keys) the VALU attention."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=32, filter_channels=32, filter_channels_dp=264, n_blocks_dec=2,
+                        n_layers_enc=1, n_block_layers=1, mel_channels=8, n_split=8)
+    sd = synthetic.make_glow_state_dict(hp, seed=13)
+    g = engine.load_glow(hp, sd)
+    rng = np.random.default_rng(14)
+    for n in (21, 790):
+        ids = synthetic.synthetic_phoneme_ids(rng, n, hp.num_symbols)
+        ref = glow_tts_np.glow_tts_infer(sd, hp, ids, None, 0.0, 0.4)
+        mel = engine.glow_infer(g, ids, 0.0, 0.4)
+        assert mel.frames[0] == ref.shape[1]
+        np.testing.assert_allclose(mel.numpy("raw")[0], ref, atol=5e-5, rtol=1e-4)
+    engine.unload(g)
+
+
+def test_fallback_kernels_for_unusual_hparams(emu_engine):
+    check_fallback_kernels(emu_engine)
+
+
 def test_denoise_kernels_match_oracle(emu_engine):
     """STFT -> spectral subtraction -> iSTFT (larynx/hifi_gan.py:171-179,
     larynx/audio.py:232-289) against the float64 numpy restatement."""

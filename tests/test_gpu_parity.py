@@ -276,6 +276,12 @@ def test_long_utterance_and_three_resident_voices(gpu_engine):
         gpu_engine.unload(g)
 
 
+def test_fallback_kernels_for_unusual_hparams(gpu_engine):
+    from tests.test_emu_pipeline import check_fallback_kernels
+
+    check_fallback_kernels(gpu_engine)
+
+
 def test_bad_ids_are_rejected(gpu_engine):
     from larynx_amd.ffi import Mi355ttsError
 
