@@ -1,0 +1,333 @@
+// mi355tts host runtime — mi355tts_glow_infer: the GlowTTS layer schedule (glow_tts/models.py:118-140, :191-209, :308-354)
+// (one translation unit: included once by mi355tts.hip, after the kernel headers)
+#pragma once
+
+// ------------------------------------------------------------------ GlowTTS forward
+static int run_layernorm(Worker* w, const float* x, const float* res, const float* g, const float* b, float* y, int C,
+                         long long bs, int ld, const int* len, int B, int Pmax, int post_relu) {
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, x, res, g, b, y, C, bs, ld, len, 0,
+                       post_relu, 1e-4f);
+  else
+    hipLaunchKernelGGL(layernorm_kernel, dim3((Pmax + 63) / 64, B), dim3(256), 0, w->stream, x, res, g, b, y, C, bs, ld, len, 0,
+                       post_relu, 1e-4f);
+  return 0;
+}
+
+extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                   float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                                   const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+  if (!ctx || !ids || !id_lens || !out) return fail(MI355TTS_ERR_INVALID, "null argument");
+  if (B <= 0 || ids_ld <= 0) return fail(MI355TTS_ERR_INVALID, "empty batch");
+  const GlowModel* gm;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->glow.find(glow);
+    if (it == ctx->glow.end()) return fail(MI355TTS_ERR_NO_MODEL, "no GlowTTS model %d", glow);
+    gm = it->second.get();
+  }
+  const mi355tts_glow_hparams& h = gm->hp;
+  int Pmax = 0;
+  for (int b = 0; b < B; ++b) {
+    if (id_lens[b] < 1 || id_lens[b] > ids_ld) return fail(MI355TTS_ERR_INVALID, "id_lens[%d]=%d outside [1,%d]", b, id_lens[b], ids_ld);
+    Pmax = std::max(Pmax, id_lens[b]);
+  }
+  const bool in_dev_ids = (flags & MI355TTS_IN_DEVICE) != 0;
+  if (!in_dev_ids) {
+    // the reference's embedding lookup raises on an out-of-range id (glow_tts/models.py:119);
+    // device-resident ids cannot be checked without a sync and are clamped by the kernel instead
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < id_lens[b]; ++t) {
+        const int64_t id = ids[(size_t)b * ids_ld + t];
+        if (id < 0 || id >= h.num_symbols)
+          return fail(MI355TTS_ERR_INVALID, "phoneme id %lld at [%d][%d] outside [0,%d)", (long long)id, b, t, h.num_symbols);
+      }
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  hipStream_t s = w->stream;
+  const float* A = gm->arena;
+  const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
+  const int k = h.kernel_size, nh = h.n_heads;
+  const int P = (Pmax + 3) & ~3;  // row stride
+  const bool in_dev = (flags & MI355TTS_IN_DEVICE) != 0;
+  const int enc_host_len = B == 1 ? id_lens[0] : -1;
+
+  // ---- encoder workspace
+  Carver cv;
+  const size_t o_len = cv.take(sizeof(int) * B);
+  const size_t o_ids = cv.take(sizeof(long long) * (size_t)B * ids_ld);
+  const size_t o_x = cv.take(sizeof(float) * (size_t)B * H * P);
+  const size_t o_t1 = cv.take(sizeof(float) * (size_t)B * H * P);
+  const size_t o_t2 = cv.take(sizeof(float) * (size_t)B * H * P);
+  const size_t o_qkv = cv.take(sizeof(float) * (size_t)B * 3 * H * P);
+  const size_t o_ffn = cv.take(sizeof(float) * (size_t)B * std::max(Fc, 2 * Fd) * P);
+  const size_t o_xm = cv.take(sizeof(float) * (size_t)B * M * P);
+  const size_t o_logw = cv.take(sizeof(float) * (size_t)B * P);
+  const size_t o_cum = cv.take(sizeof(int) * (size_t)B * P);
+  const int att_rows = ((Pmax + ATT_ROWS - 1) / ATT_ROWS) * ATT_ROWS;
+  const size_t o_sc = cv.take(sizeof(float) * (size_t)B * nh * att_rows * P);
+  const size_t enc_bytes = cv.pos;
+  CHECK(reserve(w, enc_bytes));
+  char* base = w->arena;
+  int* d_len = (int*)(base + o_len);
+  long long* d_ids = (long long*)(base + o_ids);
+  float* x = (float*)(base + o_x);
+  float* t1 = (float*)(base + o_t1);
+  float* t2 = (float*)(base + o_t2);
+  float* qkv = (float*)(base + o_qkv);
+  float* ffn = (float*)(base + o_ffn);
+  float* xm = (float*)(base + o_xm);
+  float* logw = (float*)(base + o_logw);
+  int* cum = (int*)(base + o_cum);
+  float* sc = (float*)(base + o_sc);
+
+  HIPCHECK(hipMemcpyAsync(d_len, id_lens, sizeof(int) * B, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+
+  const long long bsH = (long long)H * P;
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(embed_kernel, dim3((Pmax + 63) / 64, 8, B), dim3(256), 0, s, d_ids, ids_ld, d_len, A + gm->emb,
+                       h.num_symbols, H, std::sqrt((float)H), x, bsH, P);
+  }
+  if (h.prenet) {
+    // ConvReluNorm: conv -> LayerNorm -> ReLU (x3), then x + proj(.)  (layers.py:73-80)
+    const float* cur = x;
+    for (int i = 0; i < h.prenet_layers; ++i) {
+      ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
+      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
+      cur = t2;
+    }
+    ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
+    a.res = x;
+    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+  }
+  for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
+    const GlowLayer& L = gm->layers[l];
+    {
+      ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
+      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    }
+    {
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      const dim3 ag((Pmax + 31) / 32, nh, B);
+      const int dkh = H / nh;
+#define ATT_LAUNCH(NK)                                                                                                   \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK>), ag, dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,     \
+                     h.window_size, A + L.ek, A + L.ev, t2, bsH, P)
+      if (Pmax <= ATTM_MAXP && dkh <= 32) ATT_LAUNCH(16);
+      else if (Pmax <= ATTM_MAXP && dkh <= 64) ATT_LAUNCH(32);
+      else if (Pmax <= ATTM_MAXP && dkh <= 96) ATT_LAUNCH(48);
+      else if (Pmax <= ATTM_MAXP) ATT_LAUNCH(64);
+#undef ATT_LAUNCH
+      else
+        hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
+                           h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
+    }
+    {
+      ConvArgs a = base_args(t2, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, 0);
+      a.res = x;
+      CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      run_layernorm(w, t1, nullptr, A + L.g1, A + L.b1, x, H, bsH, P, d_len, B, Pmax, 0);
+    }
+    {  // FFN, attentions.py:375-383
+      ConvArgs a = base_args(x, bsH, P, d_len, 1, ffn, (long long)Fc * P, P, d_len, 1, 1, k / 2);
+      a.out_act = ACT_RELU;
+      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
+      c.res = x;
+      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
+    }
+  }
+  {  // proj_m and the duration predictor (models.py:133-139, 39-49)
+    ConvArgs a = base_args(x, bsH, P, d_len, 1, xm, (long long)M * P, P, d_len, 1, 1, 0);
+    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    float* d1 = ffn;
+    float* d2 = ffn + (size_t)B * Fd * P;
+    const long long bsD = (long long)Fd * P;
+    ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
+    c1.out_act = ACT_RELU;
+    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    {
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
+    }
+    ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
+    c2.out_act = ACT_RELU;
+    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    {
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
+    }
+    ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
+    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+  }
+
+  // ---- durations -> frame counts (the one host sync of the path)
+  mi355tts_mel* mel = nullptr;
+  {
+    // frames live with the result object
+    auto* m = new mi355tts_mel();
+    m->ctx = ctx;
+    m->B = B;
+    m->M = M;
+    m->ld = 0;
+    m->frames.assign(B, 0);
+    m->frames_dev = (int*)pool_alloc(ctx, sizeof(int) * B);
+    if (!m->frames_dev) {
+      delete m;
+      return fail(MI355TTS_ERR_NOMEM, "hipMalloc frames");
+    }
+    mel = m;
+  }
+  struct MelGuard {
+    mi355tts_mel* m;
+    ~MelGuard() { mel_destroy(m); }
+  } mguard{mel};
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(64), 0, s, logw, (long long)P, d_len, length_scale, h.n_sqz, cum, P,
+                       mel->frames_dev, 1 << 28);
+  }
+  if ((size_t)B > w->pinned_ints) return fail(MI355TTS_ERR_INVALID, "batch too large");
+  HIPCHECK(hipMemcpyAsync(w->pinned, mel->frames_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  int Fmax = 0;
+  for (int b = 0; b < B; ++b) {
+    mel->frames[b] = w->pinned[b];
+    Fmax = std::max(Fmax, w->pinned[b]);
+  }
+  if (noise && noise_scale != 0.f && noise_ld < Fmax)
+    return fail(MI355TTS_ERR_TOO_SMALL, "noise has %d columns but the utterance needs %d frames", noise_ld, Fmax);
+  mel->max_frames = Fmax;
+  const int Fld = (Fmax + 3) & ~3;
+  mel->ld = Fld;
+  if (Fmax == 0) {
+    mguard.m = nullptr;
+    *out = mel;
+    return 0;
+  }
+  {
+    const size_t n = (size_t)B * M * Fld * sizeof(float);
+    mel->raw_bytes = n;
+    mel->raw = (float*)pool_alloc(ctx, n);
+    mel->voc = (float*)pool_alloc(ctx, n);
+    if (!mel->raw || !mel->voc) return fail(MI355TTS_ERR_NOMEM, "hipMalloc mel");
+  }
+
+  // ---- decoder workspace (appended after the encoder's, which stays live)
+  const int nsq = h.n_sqz;
+  const int C = M * nsq, half = C / 2;
+  const int F2max = Fmax / nsq;
+  const int F2 = (F2max + 3) & ~3;
+  Carver dv;
+  dv.pos = enc_bytes;
+  const size_t o_z = dv.take(sizeof(float) * (size_t)B * C * F2);
+  const size_t o_h = dv.take(sizeof(float) * (size_t)B * H * F2);
+  const size_t o_ac = dv.take(sizeof(float) * (size_t)B * H * F2);
+  const size_t o_sk = dv.take(sizeof(float) * (size_t)B * H * F2);
+  const size_t o_nz = dv.take((noise && !in_dev) ? sizeof(float) * (size_t)B * M * noise_ld : 0);
+  if (dv.pos > w->arena_bytes) {
+    // growing would move the encoder buffers: stage the three still-live encoder
+    // outputs (x_m, cum, len) through a fresh arena instead
+    std::vector<char> keep(enc_bytes);
+    HIPCHECK(hipMemcpy(keep.data(), w->arena, enc_bytes, hipMemcpyDeviceToHost));
+    CHECK(reserve(w, dv.pos));
+    HIPCHECK(hipMemcpy(w->arena, keep.data(), enc_bytes, hipMemcpyHostToDevice));
+    base = w->arena;
+    d_len = (int*)(base + o_len);
+    xm = (float*)(base + o_xm);
+    cum = (int*)(base + o_cum);
+  }
+  float* z = (float*)(base + o_z);
+  float* hbuf = (float*)(base + o_h);
+  float* acts = (float*)(base + o_ac);
+  float* skip = (float*)(base + o_sk);
+  const float* d_noise = noise;
+  if (noise && !in_dev) {
+    float* nz = (float*)(base + o_nz);
+    HIPCHECK(hipMemcpyAsync(nz, noise, sizeof(float) * (size_t)B * M * noise_ld, hipMemcpyHostToDevice, s));
+    d_noise = nz;
+  }
+  const int* d_frames = mel->frames_dev;
+  const long long bsZ = (long long)C * F2, bsD = (long long)H * F2;
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(expand_noise_squeeze_kernel, dim3((Fmax + 255) / 256, 8, B), dim3(256), 0, s, xm, (long long)M * P, P,
+                       d_len, cum, P, d_frames, d_noise, (long long)M * noise_ld, noise_ld, noise_scale, seed, M, nsq, z,
+                       bsZ, F2);
+  }
+  // frames/n_sqz is the decoder's time axis: len = frames[b] / nsq  -> use out_mul trick via a scaled length array
+  // (frames are multiples of n_sqz; kernels take frames with a divisor where needed)
+  const int dec_host_len = B == 1 ? mel->frames[0] / nsq : -1;
+  int* d_f2 = (int*)(base + o_len);  // reuse: id lengths are no longer needed after expansion
+  {
+    // d_f2[b] = frames[b] / nsq, computed on the host side of the sync above
+    for (int b = 0; b < B; ++b) w->pinned[b] = mel->frames[b] / nsq;
+    HIPCHECK(hipMemcpyAsync(d_f2, w->pinned, sizeof(int) * B, hipMemcpyHostToDevice, s));
+  }
+  for (int blk = h.n_blocks_dec - 1; blk >= 0; --blk) {  // models.py:195-206, reversed flows
+    const GlowBlock& Bk = gm->blocks[blk];
+    {  // CouplingBlock reverse (attentions.py:119-142): h = start(x0)
+      ConvArgs a = base_args(z, bsZ, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
+      CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+    }
+    int dil = 1;
+    for (int j = 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
+      const int kd = h.kernel_size_dec;
+      ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
+      a.half = H;
+      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
+      if (j < h.n_block_layers - 1) {
+        r.res = hbuf;  // x = x + res_skip[:H]
+        r.split = H;
+      } else {
+        r.split = 0;  // last layer: everything is skip
+      }
+      r.y2 = skip;
+      r.y2_bs = bsD;
+      r.y2_ld = F2;
+      r.accum2 = j > 0;
+      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      dil *= h.dilation_rate;
+    }
+    {  // m, logs = end(wn_out);  z1 = (x1 - m) * exp(-logs)
+      ConvArgs a = base_args(skip, bsD, F2, d_f2, 1, z + (size_t)half * F2, bsZ, F2, d_f2, 1, 1, 0);
+      a.res = z + (size_t)half * F2;
+      a.half = half;
+      const bool fuse_mix = h.n_split == 4 && (half % 2) == 0;
+      if (fuse_mix) {  // InvConvNear + ActNorm ride in the coupling conv's epilogue
+        a.mix_x0 = z;
+        a.mix_w = A + Bk.winv;
+        a.mix_bias = A + Bk.an_bias;
+        a.mix_scale = A + Bk.an_scale;
+      }
+      CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      if (fuse_mix) continue;
+    }
+    {
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      hipLaunchKernelGGL(invconv_actnorm_kernel, dim3((F2max + 255) / 256, std::min(C / h.n_split, 16), B), dim3(256), 0, s, z,
+                         bsZ, F2, d_f2, 1, C, h.n_split, A + Bk.winv, A + Bk.an_bias, A + Bk.an_scale);
+    }
+  }
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(mel_finalize_kernel, dim3((Fld + 255) / 256, std::min(M, 16), B), dim3(256), 0, s, z, bsZ, F2, d_frames, M,
+                       nsq, mel->raw, mel->voc, (long long)M * Fld, Fld, to_mt(audio), audio ? 1 : 0);
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
+  mguard.m = nullptr;
+  *out = mel;
+  return 0;
+}

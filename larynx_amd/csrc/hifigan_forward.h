@@ -1,0 +1,307 @@
+// mi355tts host runtime — mi355tts_hifigan_infer: the HiFi-GAN layer schedule (hifi_gan/models.py:186-202) and the denoiser
+// (one translation unit: included once by mi355tts.hip, after the kernel headers)
+#pragma once
+
+// ------------------------------------------------------------------ HiFi-GAN forward
+extern "C" int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder) {
+  if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->hifi.find(vocoder);
+  if (it == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no HiFi-GAN model %d", vocoder);
+  return it->second->hop;
+}
+
+static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
+  std::lock_guard<std::mutex> lk(hm->bias_mu);
+  if (hm->bias_ready) return 0;
+  const int M = hm->hp.num_mels, hop = hm->hop;
+  const int zf = 88;  // the reference's all-zero mel has 88 frames (hifi_gan.py:187,198)
+  const long long N = (long long)zf * hop;
+  if (N <= DN_FFT) return fail(MI355TTS_ERR_INVALID, "vocoder hop %d too small for the 1024-point denoiser STFT", hop);
+  HIPCHECK(hipSetDevice(ctx->device));
+  std::vector<float> zeros((size_t)M * zf, 0.f);
+  int32_t fr = zf;
+  mi355tts_mel* zm = nullptr;
+  CHECK(mi355tts_mel_from_buffer(ctx, zeros.data(), &fr, 1, M, zf, nullptr, 0, &zm));
+  float* dwav = nullptr;
+  float* bias = nullptr;
+  int rc = 0;
+  if (hipMalloc(&dwav, sizeof(float) * (size_t)N) != hipSuccess || hipMalloc(&bias, sizeof(float) * (DN_FFT / 2 + 1)) != hipSuccess)
+    rc = fail(MI355TTS_ERR_NOMEM, "hipMalloc denoiser bias");
+  if (!rc) rc = mi355tts_hifigan_infer(ctx, vocoder, zm, 0.f, dwav, nullptr, N, MI355TTS_OUT_DEVICE);
+  if (!rc) {
+    Worker* w = nullptr;
+    rc = acquire_worker(ctx, &w);
+    if (!rc) {
+      WorkerGuard guard{ctx, w};
+      hipLaunchKernelGGL(stft_denoise_kernel, dim3(1, 1), dim3(256), 0, w->stream, dwav, (long long)N, zm->frames_dev, hop,
+                         (const float*)nullptr, 0.f, (float*)nullptr, 1, bias);
+      if (hipStreamSynchronize(w->stream) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "denoiser bias kernel failed");
+    }
+  }
+  mel_destroy(zm);
+  if (dwav) hipFree(dwav);
+  if (rc) {
+    if (bias) hipFree(bias);
+    return rc;
+  }
+  hm->bias_spec = bias;
+  hm->bias_ready = true;
+  return 0;
+}
+
+extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                                      float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
+  if (!ctx || !mel) return fail(MI355TTS_ERR_INVALID, "null argument");
+  HifiModel* hm;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->hifi.find(vocoder);
+    if (it == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no HiFi-GAN model %d", vocoder);
+    hm = it->second.get();
+  }
+  const mi355tts_hifigan_hparams& h = hm->hp;
+  if (mel->M != h.num_mels) return fail(MI355TTS_ERR_INVALID, "mel has %d channels, vocoder expects %d", mel->M, h.num_mels);
+  const int B = mel->B, F = mel->max_frames, hop = hm->hop;
+  const long long N = (long long)F * hop;
+  if (wav_ld < N) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)wav_ld, N);
+  const bool denoise = denoiser_strength > 0.f && F > 0;
+  if (denoise) {
+    // the reference's STFT needs more than one 1024-sample frame per utterance
+    // (larynx/audio.py:232-249 raises on shorter input)
+    for (int b = 0; b < B; ++b)
+      if ((long long)mel->frames[b] * hop <= DN_FFT)
+        return fail(MI355TTS_ERR_INVALID, "utterance %d has %d frames: too short for the denoiser", b, mel->frames[b]);
+    CHECK(ensure_denoiser_bias(ctx, hm, vocoder));
+  }
+  const bool out_dev = (flags & MI355TTS_OUT_DEVICE) != 0;
+  if (F == 0) {
+    if (!out_dev) {
+      if (wav_f32) std::memset(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld);
+      if (wav_i16) std::memset(wav_i16, 0, sizeof(int16_t) * (size_t)B * wav_ld);
+    }
+    return 0;
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  hipStream_t s = w->stream;
+  const int C0 = h.upsample_initial_channel;
+  // largest [C][L] plane over conv_pre and the stages
+  const int Fp = (F + 3) & ~3;  // row strides are multiples of 4 floats (16-byte staging loads)
+  size_t plane = (size_t)C0 * Fp;
+  {
+    long long L = F;
+    for (int i = 0; i < h.num_upsamples; ++i) {
+      L *= h.upsample_rates[i];
+      plane = std::max(plane, (size_t)(C0 >> (i + 1)) * (size_t)L);
+    }
+  }
+  const size_t Nld = (size_t)((N + 3) & ~3LL);
+  const int nk = h.num_kernels;
+  // The nk ResBlock chains of a stage are independent (MRF): run them on separate
+  // streams so their workgroups interleave — at batch 1 one conv launch has fewer
+  // tiles than the chip has SIMDs.  Each chain writes its own output; the average
+  // is taken by the consumer's staging load.
+  const bool concurrent = !ctx->serial_branches && nk >= 2 && nk <= 3;
+  if (concurrent && !w->aux[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIPCHECK(hipStreamCreateWithFlags(&w->aux[i], hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&w->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+  }
+  // concurrent chains share the chip: 300 tiles per launch measured best (sweeps of 80..1024,
+  // also per-chain values, in round 1: 6.6 ms vs 7.05 ms per utterance at 1024)
+  // tuning knob: MI355TTS_RB_TILES overrides the per-chain workgroup target of the concurrent schedule
+  static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
+  const int rb_tiles = concurrent ? (rb_env > 0 ? rb_env : 300) : 1024;
+  const int voc_host_len = B == 1 ? mel->frames[0] : -1;
+  const int nbuf = concurrent ? 2 + 4 * nk : 6;
+  Carver cv;
+  size_t o_buf[16];
+  for (int i = 0; i < nbuf; ++i) o_buf[i] = cv.take(sizeof(float) * (size_t)B * plane);
+  const size_t o_wav = cv.take(sizeof(float) * (size_t)B * Nld);
+  const size_t o_i16 = cv.take(sizeof(short) * (size_t)B * Nld);
+  const size_t o_peak = cv.take(sizeof(unsigned) * B);
+  const int Tmax = denoise ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0;
+  const size_t o_wav2 = cv.take(denoise ? sizeof(float) * (size_t)B * Nld : 0);
+  const size_t o_fbuf = cv.take(denoise ? sizeof(float) * (size_t)B * Tmax * DN_FFT : 0);
+  CHECK(reserve(w, cv.pos));
+  char* base = w->arena;
+  float* buf[16];
+  for (int i = 0; i < nbuf; ++i) buf[i] = (float*)(base + o_buf[i]);
+  float* wav = (float*)(base + o_wav);
+  short* i16 = (short*)(base + o_i16);
+  unsigned* peak = (unsigned*)(base + o_peak);
+  const int* d_frames = mel->frames_dev;
+
+  // stage input: `cur[0]` alone, or the nk chain outputs cur[0..nk) still to be averaged
+  float* cur[3] = {buf[0], nullptr, nullptr};
+  int ncur = 1;
+  float* xu = buf[1];
+  {  // conv_pre (models.py:187)
+    ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * Fp, Fp, d_frames, 1, 1, 3);
+    CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO, nullptr, 1024, voc_host_len));
+  }
+  auto set_inputs = [&](ConvArgs& a) {
+    if (ncur > 1) {
+      a.x2 = cur[1];
+      a.x3 = ncur > 2 ? cur[2] : nullptr;
+      a.in_div = (float)ncur;
+    }
+  };
+  int mul = 1;
+  int Lin = F;
+  int ldin = Fp;
+  int ch = C0;
+  int flip = 0;  // which half of the chain-output buffers this stage writes
+  for (int i = 0; i < h.num_upsamples; ++i) {
+    const int u = h.upsample_rates[i], ku = h.upsample_kernel_sizes[i];
+    const int cout = C0 >> (i + 1);
+    const int Lout = Lin * u;
+    {  // x = ups[i](leaky_relu(x, 0.1))  (models.py:189-190)
+      ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
+      set_inputs(a);
+      a.in_slope = 0.1f;
+      a.up = u;
+      a.up_pad = (ku - u) / 2;
+      CHECK(launch_conv(ctx, w, hm->ups[i], a, EPI_UPSAMPLE, B, Lin + ku / u - 1, KC_UPSAMPLE, nullptr, 1024, voc_host_len));
+    }
+    mul *= u;
+    ch = cout;
+    const long long bs = (long long)ch * Lout;
+    const float inv_nk = 1.0f / (float)nk;
+    if (concurrent) {
+      HIPCHECK(hipEventRecord(w->ev_fork, s));
+      for (int j = 1; j < nk; ++j) HIPCHECK(hipStreamWaitEvent(w->aux[j - 1], w->ev_fork, 0));
+    }
+    float* outs[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
+      const int kk = h.resblock_kernel_sizes[j];
+      hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
+      float *tb, *pa, *pb, *dst_last;
+      if (concurrent) {
+        // per-chain scratch: buf[2 + 4j .. 2 + 4j + 3] = {t, ping, out(flip 0), out(flip 1)}
+        tb = buf[2 + 4 * j];
+        pa = buf[2 + 4 * j + 1];
+        pb = buf[2 + 4 * j + 2 + (flip ^ 1)];  // last stage's output: dead once the upsampler (before the fork) has read it
+        dst_last = buf[2 + 4 * j + 2 + flip];
+      } else {
+        tb = buf[2];
+        pa = buf[3];
+        pb = buf[4];
+        dst_last = buf[5];
+      }
+      outs[j] = dst_last;
+      const float* rin = xu;
+      for (int d = 0; d < h.num_dilations; ++d) {
+        const HifiResConv& rc = hm->rb[i][j][d];
+        const bool last = d == h.num_dilations - 1;
+        float* dst = last ? dst_last : ((d & 1) ? pb : pa);
+        if (!dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
+        if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
+          {
+            const float pa_alpha = (last && !concurrent) ? inv_nk : 1.0f;
+            const int pa_accum = (last && !concurrent) ? (j > 0) : 0;
+            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
+            if (fr < 0) return fr;
+            if (fr == 0) {
+              rin = dst;
+              continue;
+            }
+          }
+          ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+          a.in_slope = 0.1f;
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
+          ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
+          c.in_slope = 0.1f;
+          c.res = rin;
+          if (last && !concurrent) {
+            c.alpha = inv_nk;
+            c.accum = j > 0;
+          }
+          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
+        } else {  // ResBlock2.forward, models.py:136-141
+          ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+          a.in_slope = 0.1f;
+          a.res = rin;
+          if (last && !concurrent) {
+            a.alpha = inv_nk;
+            a.accum = j > 0;
+          }
+          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
+        }
+        rin = dst;
+      }
+    }
+    if (concurrent) {
+      for (int j = 1; j < nk; ++j) {
+        HIPCHECK(hipEventRecord(w->ev_join[j - 1], w->aux[j - 1]));
+        HIPCHECK(hipStreamWaitEvent(s, w->ev_join[j - 1], 0));
+      }
+      for (int j = 0; j < nk; ++j) cur[j] = outs[j];
+      ncur = nk;
+      flip ^= 1;
+    } else {
+      // serial: buf[5] holds the averaged sum; rotate it with the stage-input buffer
+      std::swap(buf[5], buf[0]);
+      cur[0] = buf[0];
+      ncur = 1;
+    }
+    Lin = Lout;
+    ldin = Lout;
+  }
+  {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
+    ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
+    set_inputs(a);
+    a.in_slope = 0.01f;
+    a.out_act = ACT_TANH;
+    CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO, nullptr, 1024, voc_host_len));
+  }
+  if (denoise) {  // HiFiGanVocoder.denoise (larynx/hifi_gan.py:171-179)
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    float* wav2 = (float*)(base + o_wav2);
+    float* fbuf = (float*)(base + o_fbuf);
+    hipLaunchKernelGGL(stft_denoise_kernel, dim3(Tmax, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, hm->bias_spec,
+                       denoiser_strength, fbuf, Tmax, (float*)nullptr);
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fbuf, Tmax, d_frames, hop, wav2, (long long)Nld,
+                       (long long)Nld);
+    wav = wav2;
+  }
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
+    if (wav_i16) {
+      HIPCHECK(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
+      hipLaunchKernelGGL(absmax_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak);
+      hipLaunchKernelGGL(to_int16_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak, i16,
+                         (long long)Nld, (long long)Nld);
+    }
+  }
+  const hipMemcpyKind kind = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  for (int b = 0; b < B; ++b) {
+    if (wav_f32) {
+      HIPCHECK(hipMemcpyAsync(wav_f32 + (size_t)b * wav_ld, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, kind, s));
+      if (wav_ld > N) {
+        if (out_dev) HIPCHECK(hipMemsetAsync(wav_f32 + (size_t)b * wav_ld + N, 0, sizeof(float) * (size_t)(wav_ld - N), s));
+      }
+    }
+    if (wav_i16) {
+      HIPCHECK(hipMemcpyAsync(wav_i16 + (size_t)b * wav_ld, i16 + (size_t)b * Nld, sizeof(short) * (size_t)N, kind, s));
+      if (wav_ld > N) {
+        if (out_dev) HIPCHECK(hipMemsetAsync(wav_i16 + (size_t)b * wav_ld + N, 0, sizeof(short) * (size_t)(wav_ld - N), s));
+      }
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
+  if (!out_dev && wav_ld > N) {
+    for (int b = 0; b < B; ++b) {
+      if (wav_f32) std::memset(wav_f32 + (size_t)b * wav_ld + N, 0, sizeof(float) * (size_t)(wav_ld - N));
+      if (wav_i16) std::memset(wav_i16 + (size_t)b * wav_ld + N, 0, sizeof(int16_t) * (size_t)(wav_ld - N));
+    }
+  }
+  return 0;
+}

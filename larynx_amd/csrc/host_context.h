@@ -1,0 +1,144 @@
+// mi355tts host runtime — context, per-call workers (stream + workspace + pinned staging), device-block pool
+// (one translation unit: included once by mi355tts.hip, after the kernel headers)
+#pragma once
+
+// ------------------------------------------------------------------ context
+struct ProfEvent {
+  hipEvent_t a, b;
+  int cls;
+  double flop;
+};
+enum KClass { KC_RESBLOCK = 0, KC_UPSAMPLE, KC_VOC_IO, KC_GLOW_ENC_CONV, KC_GLOW_DEC_CONV, KC_SMALL, KC_COUNT };
+static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_mfma.hifigan_upsample",
+                                            "conv_mfma.hifigan_pre_post", "conv_mfma.glow_encoder",
+                                            "conv_mfma.glow_decoder",     "elementwise"};
+
+struct Worker {
+  hipStream_t stream = nullptr;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  size_t arena_pos = 0;
+  int* pinned = nullptr;  // pinned host staging for frame counts
+  size_t pinned_ints = 0;
+  std::vector<ProfEvent> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+  // side streams for the independent MRF branches of a HiFi-GAN stage
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_join[2] = {nullptr, nullptr};
+};
+
+struct mi355tts_ctx {
+  int device = 0;
+  std::mutex mu;
+  std::map<int, std::unique_ptr<GlowModel>> glow;
+  std::map<int, std::unique_ptr<HifiModel>> hifi;
+  int next_id = 1;
+  std::vector<Worker*> free_workers;
+  std::vector<Worker*> all_workers;
+  bool profiling = false;
+  bool serial_branches = false;
+  // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
+  // the whole device, which would serialise the concurrent per-utterance streams
+  std::vector<std::pair<void*, size_t>> mel_pool;
+  struct Acc {
+    long long launches = 0;
+    double ms = 0, flop = 0;
+  } prof[KC_COUNT];
+};
+
+struct mi355tts_mel {
+  mi355tts_ctx* ctx;
+  int B, M, ld;
+  float* raw = nullptr;   // [B][M][ld]
+  float* voc = nullptr;   // [B][M][ld]
+  int* frames_dev = nullptr;
+  std::vector<int32_t> frames;
+  int max_frames = 0;
+  size_t raw_bytes = 0;  // allocation size of raw / voc (pool bookkeeping)
+};
+
+static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->free_workers.empty()) {
+      *out = ctx->free_workers.back();
+      ctx->free_workers.pop_back();
+      (*out)->arena_pos = 0;
+      return 0;
+    }
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = new Worker();
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete w;
+    return fail(MI355TTS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  w->pinned_ints = 4096;
+  e = hipHostMalloc(&w->pinned, w->pinned_ints * sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    hipStreamDestroy(w->stream);
+    delete w;
+    return fail(MI355TTS_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->all_workers.push_back(w);
+  }
+  *out = w;
+  return 0;
+}
+
+static void drain_profile(mi355tts_ctx* ctx, Worker* w) {
+  if (w->events.empty()) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (auto& ev : w->events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      ctx->prof[ev.cls].launches++;
+      ctx->prof[ev.cls].ms += ms;
+      ctx->prof[ev.cls].flop += ev.flop;
+    }
+    w->event_pool.emplace_back(ev.a, ev.b);
+  }
+  w->events.clear();
+}
+
+static void release_worker(mi355tts_ctx* ctx, Worker* w) {
+  drain_profile(ctx, w);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->free_workers.push_back(w);
+}
+
+struct WorkerGuard {
+  mi355tts_ctx* ctx;
+  Worker* w;
+  ~WorkerGuard() {
+    if (w) release_worker(ctx, w);
+  }
+};
+
+// grow-only workspace: a call computes its total need, then carves.
+static int reserve(Worker* w, size_t bytes) {
+  if (bytes <= w->arena_bytes) return 0;
+  if (w->arena) {
+    HIPCHECK(hipStreamSynchronize(w->stream));
+    HIPCHECK(hipFree(w->arena));
+    w->arena = nullptr;
+    w->arena_bytes = 0;
+  }
+  size_t want = bytes + bytes / 8 + (1 << 20);
+  hipError_t e = hipMalloc(&w->arena, want);
+  if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc(%zu) for workspace: %s", want, hipGetErrorString(e));
+  w->arena_bytes = want;
+  return 0;
+}
+struct Carver {
+  size_t pos = 0;
+  size_t take(size_t bytes) {
+    size_t off = (pos + 255) & ~(size_t)255;
+    pos = off + bytes;
+    return off;
+  }
+};

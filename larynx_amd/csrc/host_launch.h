@@ -1,0 +1,259 @@
+// mi355tts host runtime — profiling scopes and the conv / fused-pair launchers (tile-shape choice)
+// (one translation unit: included once by mi355tts.hip, after the kernel headers)
+#pragma once
+
+// ------------------------------------------------------------------ launch helpers
+struct ProfScope {
+  mi355tts_ctx* ctx;
+  Worker* w;
+  bool on;
+  ProfEvent ev;
+  hipStream_t st;
+  ProfScope(mi355tts_ctx* c, Worker* wk, int cls, double flop, hipStream_t stream = nullptr)
+      : ctx(c), w(wk), on(c->profiling), st(stream ? stream : wk->stream) {
+    if (!on) return;
+    if (!w->event_pool.empty()) {
+      ev.a = w->event_pool.back().first;
+      ev.b = w->event_pool.back().second;
+      w->event_pool.pop_back();
+    } else {
+      if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+        on = false;
+        return;
+      }
+    }
+    ev.cls = cls;
+    ev.flop = flop;
+    hipEventRecord(ev.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(ev.b, st);
+    w->events.push_back(ev);
+  }
+};
+
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+static void launch_conv_inst(hipStream_t s, dim3 grid, const ConvArgs& a) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, CI_C, MB, NB, WN, KS, HALO, EPI>), grid, dim3(64 * WN * KS), 0, s, a);
+}
+
+// LDS halo capacity per tap count (max (K-1)*dilation the reference configs need)
+template <int K> struct ConvCfg;
+template <> struct ConvCfg<1> { static constexpr int HALO = 0; };
+template <> struct ConvCfg<2> { static constexpr int HALO = 4; };
+template <> struct ConvCfg<3> { static constexpr int HALO = 16; };
+template <> struct ConvCfg<5> { static constexpr int HALO = 28; };
+template <> struct ConvCfg<7> { static constexpr int HALO = 76; };
+template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
+
+// Tile shapes (all 512 threads):
+// (2-column-block-per-wave variants at 64/128 columns, a 256-thread variant without
+//  k-split, and one-m-tile "wide" tiles with 2 or 4 column blocks per wave were measured
+//  in round 1 and did not win overall; see profiles/r01_conv_sweep*.txt)
+//   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
+//   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
+//   NB1   : 4 time-waves x 2 k-groups, 128 columns
+//   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
+enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3 };
+static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
+
+template <int K, int EPI>
+static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvArgs& a) {
+  constexpr int HALO = ConvCfg<K>::HALO;
+  constexpr int CI_BIG = (K == 1) ? 64 : (K <= 5) ? 32 : 16;
+  constexpr int CI_SMALL = (K == 1) ? 64 : 32;
+  constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_COUPLING);
+  // the staged tile starts at the 4-aligned column t0 - roundup(pad, 4)
+  if ((K - 1) * a.dil + ((4 - a.pad % 4) % 4) > HALO)
+    return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
+  if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
+  if (MB == 1) {
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
+    return 0;
+  }
+  if constexpr (!PAIRED) {
+    if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
+    return 0;
+  }
+  return fail(MI355TTS_ERR_INVALID, "paired epilogues run on 32-row tiles (MB == 1)");
+}
+
+// `a` arrives with every tensor/epilogue field filled; this picks the tile and
+// template instance.  n_max = largest GEMM-N extent over the batch rows.
+static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
+                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1) {
+  if (n_max <= 0 || B <= 0) return 0;
+  if (B == 1 && host_len >= 0) {
+    // single utterance: the host already knows the row length, so the kernel need not
+    // start with a dependent global load of len[b]
+    if (a.in_len) {
+      a.in_const = host_len * a.in_mul;
+      a.in_len = nullptr;
+    }
+    if (a.out_len) {
+      a.out_const = host_len * a.out_mul;
+      a.out_len = nullptr;
+    }
+  }
+  if (epi == EPI_LINEAR && a.split > 0 && a.split < c.rows && (a.split % 32))
+    return fail(MI355TTS_ERR_INVALID, "row split %d must be a multiple of 32", a.split);
+  a.w = c.w;
+  a.bias = c.has_bias ? c.bias : nullptr;
+  a.noct = c.noct;
+  a.Cin = c.Cin;
+  a.rows = c.rows;
+  int MB = c.MB;
+  int ytiles = c.mtiles / MB;
+  // Tile shape: the largest tile that still yields >= min_tiles workgroups, otherwise the
+  // smallest tile.  1024 (4 per CU) is the measured sweet spot for a kernel that has the
+  // chip to itself (tools/conv_sweep.py); the three concurrent MRF chains ask for 300
+  // each — together they fill the chip, and the bigger tiles run closer to the MFMA rate.
+  auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
+  const long long want = min_tiles;
+  int shape = TILE_TINY;
+  if (tiles(256) >= want) shape = TILE_NB2;
+  else if (tiles(128) >= want) shape = TILE_NB1;
+  else if (tiles(64) >= want) shape = TILE_SMALL;
+  {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
+    static const int forced = [] {
+      const char* e = std::getenv("MI355TTS_FORCE_TILE");
+      return e ? std::atoi(e) : -1;
+    }();
+    int f = forced;
+    if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
+    if (g_pin_tile >= 0) f = g_pin_tile;
+    if (f >= TILE_SMALL && f <= TILE_LAST) shape = f;
+  }
+  // a launch that cannot even give every CU one workgroup: halve the row tile too
+  // (32-row m-tiles are independent in the packed weights; paired epilogues need both)
+  if (shape == TILE_TINY && MB == 2 && (epi == EPI_LINEAR || epi == EPI_UPSAMPLE) && tiles(32) < 256) {
+    MB = 1;
+    ytiles = (c.rows + 31) / 32;
+  }
+  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
+  const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
+  hipStream_t s = stream ? stream : w->stream;
+  ProfScope ps(ctx, w, cls, flop, s);
+  int rc = 0;
+  if (epi == EPI_LINEAR) {
+    switch (c.K) {
+      case 1: rc = launch_conv_k<1, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 3: rc = launch_conv_k<3, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 5: rc = launch_conv_k<5, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 7: rc = launch_conv_k<7, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      case 11: rc = launch_conv_k<11, EPI_LINEAR>(s, MB, shape, grid, a); break;
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d", c.K);
+    }
+  } else if (epi == EPI_GATE) {
+    switch (c.K) {
+      case 3: rc = launch_conv_k<3, EPI_GATE>(s, MB, shape, grid, a); break;
+      case 5: rc = launch_conv_k<5, EPI_GATE>(s, MB, shape, grid, a); break;
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported WaveNet kernel size %d", c.K);
+    }
+  } else if (epi == EPI_COUPLING) {
+    if (c.K == 1) rc = launch_conv_k<1, EPI_COUPLING>(s, MB, shape, grid, a);
+    else rc = fail(MI355TTS_ERR_INVALID, "coupling conv must be 1x1");
+  } else {
+    switch (c.K) {
+      case 1: rc = launch_conv_k<1, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
+      case 2: rc = launch_conv_k<2, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
+      case 3: rc = launch_conv_k<3, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported upsample taps %d", c.K);
+    }
+  }
+  return rc;
+}
+
+// Fused ResBlock1 step (conv1 -> lrelu -> conv2 -> + x) for the 32/64-channel stages.
+// Returns 1 if the geometry is not covered (caller falls back to two conv launches).
+static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs,
+                       int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s,
+                       int host_len = -1) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
+  const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
+  const int C = c1.Cout, K = c1.K;
+  if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
+      (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y)
+    return 1;
+  PairArgs a;
+  a.x = x;
+  a.y = y;
+  a.bs = bs;
+  a.ld = ld;
+  a.len = (B == 1 && host_len >= 0) ? nullptr : len;
+  a.len_mul = len_mul;
+  a.len_const = host_len * len_mul;
+  a.w1 = c1.w;
+  a.b1 = c1.bias;
+  a.w2 = c2.w;
+  a.b2 = c2.bias;
+  a.noct = c1.noct;
+  a.C = C;
+  a.dil = dil;
+  a.slope = 0.1f;
+  a.alpha = alpha;
+  a.accum = accum;
+  const int NB = (C == 32) ? 2 : nb64;
+  const int T2 = 128 * NB - (K - 1);
+  dim3 grid((Lmax + T2 - 1) / T2, 1, B);
+  const double flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
+  ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+#define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
+#define PAIR_K(KK)                                  \
+  if (C == 32) PAIR_LAUNCH(KK, 1, 2);               \
+  else if (NB == 2) PAIR_LAUNCH(KK, 2, 2);          \
+  else PAIR_LAUNCH(KK, 2, 1)
+  if (K == 3) { PAIR_K(3); }
+  else if (K == 7) { PAIR_K(7); }
+  else { PAIR_K(11); }
+#undef PAIR_K
+#undef PAIR_LAUNCH
+  return 0;
+}
+
+static ConvArgs base_args(const float* x, long long x_bs, int x_ld, const int* in_len, int in_mul, float* y, long long y_bs,
+                          int y_ld, const int* out_len, int out_mul, int dil, int pad) {
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.x_bs = x_bs;
+  a.x_ld = x_ld;
+  a.in_len = in_len;
+  a.in_mul = in_mul;
+  a.y = y;
+  a.y_bs = y_bs;
+  a.y_ld = y_ld;
+  a.out_len = out_len;
+  a.out_mul = out_mul;
+  a.dil = dil;
+  a.pad = pad;
+  a.in_slope = 1.0f;
+  a.alpha = 1.0f;
+  a.split = 1 << 30;
+  a.out_act = ACT_NONE;
+  return a;
+}
+
+static MelTransform to_mt(const mi355tts_audio_settings* s) {
+  MelTransform m;
+  std::memset(&m, 0, sizeof(m));
+  if (!s) return m;
+  m.signal_norm = s->signal_norm;
+  m.symmetric_norm = s->symmetric_norm;
+  m.clip_norm = s->clip_norm;
+  m.convert_db_to_amp = s->convert_db_to_amp;
+  m.do_drc = s->do_dynamic_range_compression;
+  m.min_level_db = s->min_level_db;
+  m.max_norm = s->max_norm;
+  m.ref_level_db = s->ref_level_db;
+  m.spec_gain = s->spec_gain;
+  return m;
+}
