@@ -53,7 +53,8 @@ def test_conv_transpose1d_matches_oracle(emu_engine, Cin, Cout, K, u, L):
 
 
 @pytest.mark.parametrize("shape", [0, 1, 2, 3])
-@pytest.mark.parametrize("Cin,Cout,K,dil,L", [(24, 40, 3, 3, 300), (16, 16, 11, 5, 520), (40, 33, 1, 1, 290), (16, 72, 7, 1, 300)])
+@pytest.mark.parametrize("Cin,Cout,K,dil,L", [(24, 40, 3, 3, 300), (16, 16, 11, 5, 520), (40, 33, 1, 1, 290), (16, 72, 7, 1, 300),
+                                              (72, 70, 11, 5, 300)])  # the last one: 64-row k=11 tiles (LDS weight ring at 64 columns)
 def test_conv1d_every_tile_shape(emu_engine, monkeypatch, shape, Cin, Cout, K, dil, L):
     """The launcher picks the tile shape from the problem size; pin each one."""
     monkeypatch.setenv("MI355TTS_FORCE_TILE_DYNAMIC", str(shape))
