@@ -219,8 +219,8 @@ class Engine:
         """Returns (wav_f32 [B, N] or None, wav_i16 [B, N] or None), N = max_frames*hop;
         row b holds frames[b]*hop samples followed by zeros."""
         n = mel.max_frames * self.hop(vocoder)
-        f32 = np.zeros((mel.batch, n), np.float32) if want_float else None
-        i16 = np.zeros((mel.batch, n), np.int16) if want_int16 else None
+        f32 = np.empty((mel.batch, n), np.float32) if want_float else None
+        i16 = np.empty((mel.batch, n), np.int16) if want_int16 else None
         ffi.check(
             self.lib,
             self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, float(denoiser_strength), ffi.ptr(f32), ffi.ptr(i16), n, 0),
