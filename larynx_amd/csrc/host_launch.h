@@ -53,15 +53,16 @@ template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 //  in round 1 and did not win overall; see profiles/r01_conv_sweep*.txt)
 //   TINY  : 1 time-wave  x 8 k-groups, 32 columns  — launches with only a handful of tiles (GlowTTS at batch 1)
 //   SMALL : 2 time-waves x 4 k-groups, 64 columns  — few-tile launches (stage 0 at batch 1)
-//   NB1   : 4 time-waves x 2 k-groups, 128 columns
+//   W128  : 2 time-waves x 4 k-groups, 128 columns x ONE 32-row m-tile, 2 column blocks per wave — half the
+//           weight bytes per MFMA of a 64-row tile and 4 k-groups; measured 7-14 % faster than the
+//           4 x 2-wave 64-row tile it replaced, and equal or better than SMALL at the same tile count
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_NB1 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3 };
+enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
 static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvArgs& a) {
   constexpr int HALO = ConvCfg<K>::HALO;
-  constexpr int CI_BIG = (K == 1) ? 64 : (K <= 5) ? 32 : 16;
   constexpr int CI_SMALL = (K == 1) ? 64 : 32;
   constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_COUPLING);
   // the staged tile starts at the 4-aligned column t0 - roundup(pad, 4)
@@ -71,14 +72,14 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   if (MB == 1) {
     if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 1, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_W128) launch_conv_inst<K, 32, 1, 2, 2, 4, HALO, EPI>(s, grid, a);
     else launch_conv_inst<K, 16, 1, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
   if constexpr (!PAIRED) {
     if (shape == TILE_TINY) launch_conv_inst<K, 64, 2, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 2, 1, 2, 4, HALO, EPI>(s, grid, a);
-    else if (shape == TILE_NB1) launch_conv_inst<K, CI_BIG, 2, 1, 4, 2, HALO, EPI>(s, grid, a);
+    else if (shape == TILE_W128) return fail(MI355TTS_ERR_INVALID, "internal: the 128-column tile is one m-tile high");
     else launch_conv_inst<K, 16, 2, 2, 4, 2, HALO, EPI>(s, grid, a);
     return 0;
   }
@@ -115,11 +116,12 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   // smallest tile.  1024 (4 per CU) is the measured sweet spot for a kernel that has the
   // chip to itself (tools/conv_sweep.py); the three concurrent MRF chains ask for 300
   // each — together they fill the chip, and the bigger tiles run closer to the MFMA rate.
-  auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * ytiles * B; };
+  const int rows32 = (c.rows + 31) / 32;  // m-tiles when a workgroup is one m-tile high (the 128-column shape)
+  auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * (width == 128 ? rows32 : ytiles) * B; };
   const long long want = min_tiles;
   int shape = TILE_TINY;
   if (tiles(256) >= want) shape = TILE_NB2;
-  else if (tiles(128) >= want) shape = TILE_NB1;
+  else if (tiles(128) >= want) shape = TILE_W128;
   else if (tiles(64) >= want) shape = TILE_SMALL;
   {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
     static const int forced = [] {
@@ -135,7 +137,11 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   // (32-row m-tiles are independent in the packed weights; paired epilogues need both)
   if (shape == TILE_TINY && MB == 2 && (epi == EPI_LINEAR || epi == EPI_UPSAMPLE) && tiles(32) < 256) {
     MB = 1;
-    ytiles = (c.rows + 31) / 32;
+    ytiles = rows32;
+  }
+  if (shape == TILE_W128 && MB == 2) {
+    MB = 1;
+    ytiles = rows32;
   }
   const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
