@@ -1,0 +1,66 @@
+"""Compile-time guard on the properties the measured performance rests on: no kernel
+spills to scratch, and the tile shapes that are meant to run two workgroups per CU stay
+within 128 VGPRs and 80 KB of LDS.  (hipcc's kernel-resource-usage remarks; no GPU.)"""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+SRC = REPO / "larynx_amd" / "csrc" / "mi355tts.hip"
+
+
+@pytest.fixture(scope="module")
+def resources(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).is_file():
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("res") / "dev.o"
+    proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
+                           "-Rpass-analysis=kernel-resource-usage", str(SRC), "-o", str(out)],
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    table = {}
+    for block in re.split(r"remark: [^\n]*Function Name: ", proc.stderr)[1:]:
+        name = block.split()[0]
+
+        def num(key):
+            m = re.search(key + r": (\d+)", block)
+            return int(m.group(1)) if m else -1
+
+        table[name] = dict(vgprs=num("VGPRs"), scratch=num(r"ScratchSize \[bytes/lane\]"), lds=num(r"LDS Size \[bytes/block\]"),
+                           occupancy=num(r"Occupancy \[waves/SIMD\]"))
+    assert len(table) > 50
+    return table
+
+
+def conv_variants(table):
+    """(K, CI_C, MB, NB, WN, KS, HALO, EPI) -> resources, decoded from the mangled names."""
+    out = {}
+    for name, r in table.items():
+        m = re.match(r"_ZN8mi355tts16conv_mfma_kernelI((?:Li\d+E){8})", name)
+        if m:
+            out[tuple(int(v) for v in re.findall(r"Li(\d+)E", m.group(1)))] = r
+    return out
+
+
+def test_no_used_kernel_spills(resources):
+    # resblock_pair_kernel<K, 2, 2> (64 channels x 256 columns) is instantiated but never launched (it lost the sweep)
+    spilled = {n: r["scratch"] for n, r in resources.items() if r["scratch"] > 0 and "resblock_pair_kernelILi" not in n}
+    assert not spilled, spilled
+    pair_used = {n: r for n, r in resources.items() if re.search(r"resblock_pair_kernelILi\d+ELi(1ELi2|2ELi1)E", n)}
+    assert len(pair_used) == 6 and all(r["scratch"] == 0 for r in pair_used.values())
+
+
+def test_two_workgroups_per_cu_where_the_schedule_counts_on_it(resources):
+    conv = conv_variants(resources)
+    assert conv
+    for (K, ci, MB, NB, WN, KS, halo, epi), r in conv.items():
+        if epi == 0 and NB == 1 and MB == 2:  # the 64-row one-column-block LINEAR tiles (stages 0/1 of the vocoder)
+            assert r["vgprs"] <= 128 and r["lds"] <= 80 * 1024, ((K, ci, MB, NB, WN, KS), r)
+        if NB == 2 and MB == 1 and WN == 2 and KS == 4 and epi == 0:  # the 128-column tile
+            assert r["vgprs"] <= 128 and r["lds"] <= 80 * 1024, ((K, ci, MB, NB, WN, KS), r)
+    # every workgroup of 512 threads needs at least 2 waves per SIMD
+    assert all(r["occupancy"] >= 2 for r in conv.values())
