@@ -209,6 +209,21 @@ class Engine:
         )
         return MelBatch(self, out.value)
 
+    def mel_from_device(self, device_ptr: int, frames, channels: int, ld: int, audio_settings=None) -> MelBatch:
+        """Wrap a mel that already lives in device memory ([B][channels][ld] fp32, e.g. a
+        torch tensor's `data_ptr()`); `frames` gives each row's valid length."""
+        fr = np.ascontiguousarray(frames, np.int32)
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        out = C.c_void_p()
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_mel_from_buffer(
+                self._ctx, C.c_void_p(int(device_ptr)), fr.ctypes.data_as(C.POINTER(C.c_int32)), len(fr), int(channels), int(ld),
+                C.byref(a) if a is not None else None, ffi.IN_DEVICE, C.byref(out),
+            ),
+        )
+        return MelBatch(self, out.value)
+
     def hop(self, vocoder: int) -> int:
         if vocoder not in self._hops:
             self._hops[vocoder] = ffi.check(self.lib, self.lib.mi355tts_hifigan_hop(self._ctx, vocoder))

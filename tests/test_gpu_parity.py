@@ -276,6 +276,34 @@ def test_long_utterance_and_three_resident_voices(gpu_engine):
         gpu_engine.unload(g)
 
 
+def test_device_resident_mel_input(gpu_engine):
+    """`mi355tts_mel_from_buffer` with MI355TTS_IN_DEVICE: a mel produced elsewhere on the
+    GPU (here a raw hipMalloc buffer) goes to the vocoder without a host round trip and
+    gives the same waveform as the host-array path, including the fused mel transforms."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
+    _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_LOW)
+    s = ljspeech_audio_settings()
+    rng = np.random.default_rng(17)
+    raw = (0.57 + 0.2 * rng.standard_normal((2, 80, 96))).astype(np.float32)
+    frames = np.array([96, 70], np.int32)
+    host = gpu_engine.mel_from_numpy(raw, frames=frames, audio_settings=s)
+    w_host, i_host = gpu_engine.hifigan_infer(v, host)
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(raw.nbytes)) == 0
+    try:
+        assert hip.hipMemcpy(dptr, raw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(raw.nbytes), 1) == 0  # hipMemcpyHostToDevice
+        dev = gpu_engine.mel_from_device(dptr.value, frames, 80, 96, audio_settings=s)
+        w_dev, i_dev = gpu_engine.hifigan_infer(v, dev)
+        dev.free()
+    finally:
+        hip.hipFree(dptr)
+    assert np.array_equal(w_host, w_dev) and np.array_equal(i_host, i_dev)
+    ref = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_LOW, audio_np.mel_to_vocoder_input(raw[1, :, :70], s))
+    assert np.sqrt(np.mean((w_dev[1, : 70 * 256] - ref) ** 2)) <= 2e-5 and np.all(w_dev[1, 70 * 256 :] == 0)
+
+
 def test_fallback_kernels_for_unusual_hparams(gpu_engine):
     from tests.test_emu_pipeline import check_fallback_kernels
 
