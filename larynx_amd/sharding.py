@@ -46,7 +46,10 @@ def broadcast_blob(blob: typing.Optional[np.ndarray], numel: int, device, src: i
 
 
 def load_models_broadcast(engine, glow_hp, voc_hp, glow_sd=None, voc_sd=None, device="cpu"):
-    """Fold on rank 0, broadcast, load from the receive buffer on every rank."""
+    """Fold on rank 0, broadcast, load from the receive buffer on every rank.
+    With `device="cuda:N"` the process group and torch's GPU state must have been set up
+    BEFORE `engine` was created (torch wheels carry their own HIP runtime; see
+    INTEGRATION.md "Sharing a process with PyTorch")."""
     import torch.distributed as dist
 
     from . import ffi
