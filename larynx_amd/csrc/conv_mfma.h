@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
       for (int nb = 0; nb < NB; ++nb) bcur[j][nb] = xt[(2 * j) * XW + nb * 32];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      // issue the loads for later steps first, then this step's MFMAs
+      // the loads for later steps and this step's MFMAs (interleaved by the hints below)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
         if (!MI355TTS_ABLATE(a, 2)) ar[(s + RD - 1) % RD][mb] = wq[mb][a_index(chunk, s + RD - 1)];
@@ -335,7 +335,12 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) bnxt[j][nb] = bp[(2 * j) * XW + nb * 32];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // With two or more accumulators per wave, consecutive MFMAs are independent and the
+      // fillers are interleaved with them (below).  With ONE accumulator every MFMA depends
+      // on the previous one, and a filler between two dependent MFMAs costs ~40 cycles
+      // (MI355X_MICROARCH.md): there the fillers go first and the MFMAs stay back to back.
+      constexpr bool INTERLEAVE = MB * NB >= 2;
+      if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -346,6 +351,20 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[j][nb], acc[mb][nb], 0, 0, 0);
         }
+      }
+      // Issue order inside the step (sched_group_barrier: 0x008 = MFMA, 0x020 = VMEM read,
+      // 0x100 = LDS read): each filler — the fragment loads for step s+RD-1, the LDS reads
+      // for step s+1 — goes right behind an MFMA, so it issues in the shadow of that MFMA's
+      // 64 cycles instead of in a gap before the burst (−1…−3 % on the ResBlock convs in the
+      // pipeline trace, up to −9 % in the per-layer sweep).
+      if constexpr (INTERLEAVE) {
+#pragma unroll
+        for (int i = 0; i < 4 * MB * NB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < MB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          else if (i < MB + 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (s + 1 < S) {
 #pragma unroll
