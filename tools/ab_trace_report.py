@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Compare the per-kernel average durations of the two runs tools/ab_trace.sh left under
-gpurun_out/ab0 and gpurun_out/ab1 (first argument of the script = ab0)."""
+"""Compare per-kernel average durations of the A B A B runs tools/ab_trace.sh left under
+gpurun_out/ab0..ab3 (A = first library argument: runs 0 and 2; B: runs 1 and 3)."""
 import csv
 import glob
 import re
@@ -15,13 +15,23 @@ def load(i):
     return d
 
 
-a, b = load(0), load(1)
+runs = [load(i) for i in range(4)]
+
+
+def avg(name, idx):
+    vals = [runs[i][name][1] for i in idx if name in runs[i]]
+    return sum(vals) / len(vals) if vals else None
+
+
 ta = tb = 0.0
-for n, (c, us) in sorted(a.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:22]:
-    if n in b:
-        print(f"{n:55s} {c:5d} {us:8.1f} -> {b[n][1]:8.1f}  {100 * (b[n][1] / us - 1):+.1f}%")
-for n, (c, us) in a.items():
-    if n in b:
-        ta += c * us
-        tb += b[n][0] * b[n][1]
+names = sorted(runs[0], key=lambda n: -runs[0][n][0] * runs[0][n][1])
+for n in names:
+    a, b = avg(n, (0, 2)), avg(n, (1, 3))
+    if a is None or b is None:
+        continue
+    c = runs[0][n][0]
+    ta += c * a
+    tb += c * b
+    if names.index(n) < 22:
+        print(f"{n:55s} {c:5d} {a:8.1f} -> {b:8.1f}  {100 * (b / a - 1):+.1f}%   (A runs {runs[0][n][1]:.1f}/{runs[2][n][1]:.1f}, B runs {runs[1][n][1]:.1f}/{runs[3][n][1]:.1f})")
 print(f"total kernel time: {ta / 1e3:.2f} ms -> {tb / 1e3:.2f} ms ({100 * (tb / ta - 1):+.2f}%)")
