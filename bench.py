@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--quality", default="high")
     ap.add_argument("--length-scale", type=float, default=0.65,
                     help="GlowTTS length_scale; 0.65 puts the synthetic 120-id utterances at SURVEY's standard ~624 frames")
-    ap.add_argument("--concurrency", type=int, default=3,
+    ap.add_argument("--concurrency", type=int, default=6,
                     help="utterances in flight per GPU in the timed region (host threads, each batch-1 call on its own "
                          "HIP streams — the reference's ThreadPoolExecutor pattern); the single-stream latency is "
                          "measured and reported next to it")

@@ -100,11 +100,18 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   }
   const size_t Nld = (size_t)((N + 3) & ~3LL);
   const int nk = h.num_kernels;
-  // The nk ResBlock chains of a stage are independent (MRF): run them on separate
-  // streams so their workgroups interleave — at batch 1 one conv launch has fewer
-  // tiles than the chip has SIMDs.  Each chain writes its own output; the average
-  // is taken by the consumer's staging load.
-  const bool concurrent = !ctx->serial_branches && nk >= 2 && nk <= 3;
+  // The nk ResBlock chains of a stage are independent (MRF).  Each chain writes its own
+  // output and the average is taken by the consumer's staging load (`split_out`).  A call
+  // that has the GPU to itself also runs the chains on separate streams so their workgroups
+  // interleave — at batch 1 one conv launch has fewer tiles than the chip has SIMDs
+  // (`concurrent`); when other calls are in flight they fill the chip, and forking would only
+  // make 3 x calls streams contend for the runtime's 4 hardware queues, so the call stays on
+  // one stream (measured: 3-6 calls in flight, +8 % utterances/s).  Both forms compute the
+  // same values in the same order: results do not depend on the load.
+  // `serial_branches` (profiling / tests) additionally folds the average into the chains'
+  // last epilogues (in-place accumulation, one output buffer).
+  const bool split_out = !ctx->serial_branches && nk >= 2 && nk <= 3;
+  const bool concurrent = split_out && !(ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1);
   if (concurrent && !w->aux[0]) {
     for (int i = 0; i < 2; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&w->aux[i], hipStreamNonBlocking));
@@ -112,13 +119,14 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
     HIPCHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
   }
-  // concurrent chains share the chip: 300 tiles per launch measured best (sweeps of 80..1024,
-  // also per-chain values, in round 1: 6.6 ms vs 7.05 ms per utterance at 1024)
-  // tuning knob: MI355TTS_RB_TILES overrides the per-chain workgroup target of the concurrent schedule
+  // One workgroup target for the ResBlock launches in every schedule: the tile shape fixes the
+  // k-split and with it the summation order, so a load-dependent choice would make results
+  // depend on the load.  (With the final tile set 300, 700 and 1024 measured the same within
+  // noise for the forked schedule.)  Tuning knob: MI355TTS_RB_TILES.
   static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
-  const int rb_tiles = concurrent ? (rb_env > 0 ? rb_env : 300) : 1024;
+  const int rb_tiles = rb_env > 0 ? rb_env : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
-  const int nbuf = concurrent ? 2 + 4 * nk : 6;
+  const int nbuf = split_out ? 2 + 4 * nk : 6;
   Carver cv;
   size_t o_buf[16];
   for (int i = 0; i < nbuf; ++i) o_buf[i] = cv.take(sizeof(float) * (size_t)B * plane);
@@ -182,7 +190,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
       const int kk = h.resblock_kernel_sizes[j];
       hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
       float *tb, *pa, *pb, *dst_last;
-      if (concurrent) {
+      if (split_out) {
         // per-chain scratch: buf[2 + 4j .. 2 + 4j + 3] = {t, ping, out(flip 0), out(flip 1)}
         tb = buf[2 + 4 * j];
         pa = buf[2 + 4 * j + 1];
@@ -203,8 +211,8 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
         if (!dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
         if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
           {
-            const float pa_alpha = (last && !concurrent) ? inv_nk : 1.0f;
-            const int pa_accum = (last && !concurrent) ? (j > 0) : 0;
+            const float pa_alpha = (last && !split_out) ? inv_nk : 1.0f;
+            const int pa_accum = (last && !split_out) ? (j > 0) : 0;
             const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
             if (fr < 0) return fr;
             if (fr == 0) {
@@ -218,7 +226,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
           c.in_slope = 0.1f;
           c.res = rin;
-          if (last && !concurrent) {
+          if (last && !split_out) {
             c.alpha = inv_nk;
             c.accum = j > 0;
           }
@@ -227,7 +235,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
           a.res = rin;
-          if (last && !concurrent) {
+          if (last && !split_out) {
             a.alpha = inv_nk;
             a.accum = j > 0;
           }
@@ -241,6 +249,8 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
         HIPCHECK(hipEventRecord(w->ev_join[j - 1], w->aux[j - 1]));
         HIPCHECK(hipStreamWaitEvent(s, w->ev_join[j - 1], 0));
       }
+    }
+    if (split_out) {
       for (int j = 0; j < nk; ++j) cur[j] = outs[j];
       ncur = nk;
       flip ^= 1;

@@ -38,6 +38,10 @@ struct mi355tts_ctx {
   std::vector<Worker*> all_workers;
   bool profiling = false;
   bool serial_branches = false;
+  // calls currently holding a worker; with more than one in flight the vocoder keeps each
+  // call on ONE stream (the other calls fill the chip) instead of forking its MRF chains
+  std::atomic<int> active_calls{0};
+  bool adaptive_schedule = true;
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;
@@ -65,6 +69,7 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
       *out = ctx->free_workers.back();
       ctx->free_workers.pop_back();
       (*out)->arena_pos = 0;
+      ctx->active_calls.fetch_add(1, std::memory_order_relaxed);
       return 0;
     }
   }
@@ -86,6 +91,7 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->all_workers.push_back(w);
   }
+  ctx->active_calls.fetch_add(1, std::memory_order_relaxed);
   *out = w;
   return 0;
 }
@@ -106,6 +112,7 @@ static void drain_profile(mi355tts_ctx* ctx, Worker* w) {
 }
 
 static void release_worker(mi355tts_ctx* ctx, Worker* w) {
+  ctx->active_calls.fetch_sub(1, std::memory_order_relaxed);
   drain_profile(ctx, w);
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->free_workers.push_back(w);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -751,6 +752,10 @@ extern "C" int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled) {
 extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(MI355TTS_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (std::strcmp(name, "adaptive_schedule") == 0) {
+    ctx->adaptive_schedule = value != 0;
+    return 0;
+  }
   if (std::strcmp(name, "serial_branches") == 0) {
     ctx->serial_branches = value != 0;
     return 0;
