@@ -140,6 +140,37 @@ int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder);
 int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
                            float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags);
 
+/* The same call with the SSML pause padding `_sentence_task` applies on the host with np.pad
+ * (larynx/__init__.py:277-283) done by the int16 kernel: per row `pad_before` zero samples,
+ * the audio, then zeros (at least `pad_after`) up to wav_ld.  wav_ld >= pad_before +
+ * max_frames*hop + pad_after. */
+int mi355tts_hifigan_infer_padded(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                                  float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags, int32_t pad_before,
+                                  int32_t pad_after);
+
+/* ---- fused call: replaces the model half of _sentence_task -------------------
+ * (larynx/__init__.py:229-283: phonemes_to_mels -> mel transforms -> mels_to_audio -> pause
+ * padding) with ONE call on one stream: arguments as in mi355tts_glow_infer +
+ * mi355tts_hifigan_infer_padded.  `frames_out[b]` receives each row's mel frame count (row b
+ * of the output holds pad_before + frames_out[b]*hop samples of padding + audio, then zeros).
+ * The frame count is data dependent: if `wav_ld` turns out too small the call returns
+ * MI355TTS_ERR_TOO_SMALL with frames_out filled, and the caller retries with a larger buffer.
+ * MI355TTS_IN_DEVICE applies to ids / noise, MI355TTS_OUT_DEVICE to the waveform pointers. */
+int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
+                        int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                        const mi355tts_audio_settings* audio, float denoiser_strength, int32_t pad_before,
+                        int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16, int64_t wav_ld,
+                        uint32_t flags);
+
+/* Serving set-up (the reference warms its model caches the same way, larynx/__init__.py:290,412):
+ * pre-create `workers` per-call workers (stream, side streams, pinned staging) and size
+ * their workspaces and the result-block pool for calls of up to max_batch rows x max_ids ids
+ * x max_frames mel frames (+ max_pad_samples of pause padding; denoiser != 0 also sizes the
+ * STFT scratch), so that no steady-state call allocates device memory.  glow / vocoder may
+ * be 0 to size for one model only. */
+int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vocoder, int max_batch, int max_ids, int max_frames,
+                     int denoiser, int max_pad_samples);
+
 /* ---- single operators (kernel-level parity tests, drop-in conv) ------------- */
 /* y[B][Cout][L] = act_out(bias + conv1d(lrelu_slope(x[B][Cin][L]), w[Cout][Cin][K], dilation, "same" padding)) */
 int mi355tts_op_conv1d(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const int32_t* lens, const float* w,
@@ -152,6 +183,11 @@ int mi355tts_op_conv_transpose1d(mi355tts_ctx* ctx, const float* x, int B, int C
  * (host buffers), N a multiple of 256 and > 1024 */
 int mi355tts_op_denoise(mi355tts_ctx* ctx, const float* wav, int B, int64_t N, const float* bias_spec, float strength,
                         float* out);
+
+/* out[B][C][T] (host) = the device noise generator's N(0,1) draw for (seed, row, channel, frame) —
+ * the stand-in for torch.randn_like (glow_tts/models.py:348) that mi355tts_glow_infer uses when
+ * `noise` is NULL; exposed so its distribution can be tested. */
+int mi355tts_op_gauss_noise(mi355tts_ctx* ctx, uint64_t seed, int B, int C, int T, float* out);
 
 /* Kernel micro-benchmark: `iters` back-to-back launches of the conv kernel on
  * device-resident random data of the given geometry (tile_shape -1 = the
@@ -167,7 +203,8 @@ int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, in
 int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
 /* options: "serial_branches" (0/1) — run the three MRF ResBlock chains of a
  * HiFi-GAN stage one after another on one stream instead of concurrently on
- * three (used when timing single kernels). */
+ * three (used when timing single kernels); "adaptive_schedule" (0/1, default 1) —
+ * fork the MRF chains onto side streams only while no other call is in flight. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);

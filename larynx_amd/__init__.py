@@ -78,15 +78,21 @@ def sentence_task(text: str, phoneme_ids, audio_settings, tts_model, tts_setting
         from .glow_tts import mels_as_numpy
 
         mels = vocoder_model.engine.mel_from_numpy(mels_as_numpy(mels), audio_settings=audio_settings)
-    t2 = time.perf_counter()
-    audio = vocoder_model.mels_to_audio(mels, settings=vocoder_settings)
-    t3 = time.perf_counter()
-    _LOGGER.debug("Got audio in %s second(s) (shape=%s, text='%s')", t3 - t2, audio.shape, text)
     sample_rate = audio_settings.sample_rate if audio_settings is not None else 22050
-    dur = audio.shape[-1] / sample_rate
-    _LOGGER.debug("Real-time factor: %0.2f (infer=%0.2f sec, audio=%0.2f sec)", (t3 - t0) / dur if dur > 0 else 0.0, t3 - t0, dur)
     before = max(0, (pause_before_ms * sample_rate) // 1000)
     after = max(0, (pause_after_ms * sample_rate) // 1000)
+    t2 = time.perf_counter()
+    padded = getattr(vocoder_model, "mels_to_audio_padded", None)
+    if padded is not None and (before or after):
+        # SSML pauses written by the device's int16 kernel instead of np.pad (same samples)
+        audio = padded(mels, vocoder_settings, before, after)
+        before = after = 0
+    else:
+        audio = vocoder_model.mels_to_audio(mels, settings=vocoder_settings)
+    t3 = time.perf_counter()
+    _LOGGER.debug("Got audio in %s second(s) (shape=%s, text='%s')", t3 - t2, audio.shape, text)
+    dur = audio.shape[-1] / sample_rate
+    _LOGGER.debug("Real-time factor: %0.2f (infer=%0.2f sec, audio=%0.2f sec)", (t3 - t0) / dur if dur > 0 else 0.0, t3 - t0, dur)
     if before or after:
         audio = np.pad(audio, pad_width=(before, after), constant_values=0)
     return audio

@@ -14,75 +14,135 @@ static int run_layernorm(Worker* w, const float* x, const float* res, const floa
   return 0;
 }
 
-extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
-                                   float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
-                                   const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
-  if (!ctx || !ids || !id_lens || !out) return fail(MI355TTS_ERR_INVALID, "null argument");
-  if (B <= 0 || ids_ld <= 0) return fail(MI355TTS_ERR_INVALID, "empty batch");
-  const GlowModel* gm;
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->glow.find(glow);
-    if (it == ctx->glow.end()) return fail(MI355TTS_ERR_NO_MODEL, "no GlowTTS model %d", glow);
-    gm = it->second.get();
-  }
-  const mi355tts_glow_hparams& h = gm->hp;
+struct GlowCall {
+  const int64_t* ids = nullptr;
+  const int32_t* id_lens = nullptr;
+  int B = 0, ids_ld = 0;
+  float noise_scale = 0.667f, length_scale = 1.0f;
+  const float* noise = nullptr;
+  int noise_ld = 0;
+  uint64_t seed = 0;
+  const mi355tts_audio_settings* audio = nullptr;
+  uint32_t flags = 0;
+};
+
+static int find_glow(mi355tts_ctx* ctx, int glow, const GlowModel** out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->glow.find(glow);
+  if (it == ctx->glow.end()) return fail(MI355TTS_ERR_NO_MODEL, "no GlowTTS model %d", glow);
+  *out = it->second.get();
+  return 0;
+}
+
+static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) {
+  if (!c.ids || !c.id_lens) return fail(MI355TTS_ERR_INVALID, "null argument");
+  if (c.B <= 0 || c.ids_ld <= 0) return fail(MI355TTS_ERR_INVALID, "empty batch");
   int Pmax = 0;
-  for (int b = 0; b < B; ++b) {
-    if (id_lens[b] < 1 || id_lens[b] > ids_ld) return fail(MI355TTS_ERR_INVALID, "id_lens[%d]=%d outside [1,%d]", b, id_lens[b], ids_ld);
-    Pmax = std::max(Pmax, id_lens[b]);
+  for (int b = 0; b < c.B; ++b) {
+    if (c.id_lens[b] < 1 || c.id_lens[b] > c.ids_ld)
+      return fail(MI355TTS_ERR_INVALID, "id_lens[%d]=%d outside [1,%d]", b, c.id_lens[b], c.ids_ld);
+    Pmax = std::max(Pmax, c.id_lens[b]);
   }
-  const bool in_dev_ids = (flags & MI355TTS_IN_DEVICE) != 0;
-  if (!in_dev_ids) {
+  if (!(c.flags & MI355TTS_IN_DEVICE)) {
     // the reference's embedding lookup raises on an out-of-range id (glow_tts/models.py:119);
     // device-resident ids cannot be checked without a sync and are clamped by the kernel instead
-    for (int b = 0; b < B; ++b)
-      for (int t = 0; t < id_lens[b]; ++t) {
-        const int64_t id = ids[(size_t)b * ids_ld + t];
-        if (id < 0 || id >= h.num_symbols)
-          return fail(MI355TTS_ERR_INVALID, "phoneme id %lld at [%d][%d] outside [0,%d)", (long long)id, b, t, h.num_symbols);
+    for (int b = 0; b < c.B; ++b)
+      for (int t = 0; t < c.id_lens[b]; ++t) {
+        const int64_t id = c.ids[(size_t)b * c.ids_ld + t];
+        if (id < 0 || id >= gm->hp.num_symbols)
+          return fail(MI355TTS_ERR_INVALID, "phoneme id %lld at [%d][%d] outside [0,%d)", (long long)id, b, t, gm->hp.num_symbols);
       }
   }
-  HIPCHECK(hipSetDevice(ctx->device));
-  Worker* w = nullptr;
-  CHECK(acquire_worker(ctx, &w));
-  WorkerGuard guard{ctx, w};
+  *Pmax_out = Pmax;
+  return 0;
+}
+
+// Encoder workspace of one call: ONE definition for the forward pass and mi355tts_reserve.
+struct GlowEncLayout {
+  size_t o_len, o_ids, o_x, o_t1, o_t2, o_qkv, o_ffn, o_xm, o_logw, o_cum, o_sc, total;
+  int P, att_rows;
+};
+static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int ids_ld, int Pmax) {
+  GlowEncLayout L;
+  const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
+  L.P = (Pmax + 3) & ~3;
+  const int P = L.P;
+  Carver cv;
+  L.o_len = cv.take(sizeof(int) * B);
+  L.o_ids = cv.take(sizeof(long long) * (size_t)B * ids_ld);
+  L.o_x = cv.take(sizeof(float) * (size_t)B * H * P);
+  L.o_t1 = cv.take(sizeof(float) * (size_t)B * H * P);
+  L.o_t2 = cv.take(sizeof(float) * (size_t)B * H * P);
+  L.o_qkv = cv.take(sizeof(float) * (size_t)B * 3 * H * P);
+  L.o_ffn = cv.take(sizeof(float) * (size_t)B * std::max(Fc, 2 * Fd) * P);
+  L.o_xm = cv.take(sizeof(float) * (size_t)B * M * P);
+  L.o_logw = cv.take(sizeof(float) * (size_t)B * P);
+  L.o_cum = cv.take(sizeof(int) * (size_t)B * P);
+  L.att_rows = ((Pmax + ATT_ROWS - 1) / ATT_ROWS) * ATT_ROWS;
+  // score scratch: only the VALU attention fallback (P > ATTM_MAXP) uses it
+  L.o_sc = cv.take(Pmax > ATTM_MAXP ? sizeof(float) * (size_t)B * h.n_heads * L.att_rows * P : 0);
+  L.total = cv.pos;
+  return L;
+}
+struct GlowDecLayout {
+  size_t o_z, o_h, o_ac, o_sk, o_nz, total;
+};
+static GlowDecLayout glow_dec_layout(const mi355tts_glow_hparams& h, size_t enc_bytes, int B, int Fmax, size_t host_noise_floats) {
+  GlowDecLayout L;
+  const int H = h.hidden_channels, C = h.mel_channels * h.n_sqz;
+  const int F2 = (Fmax / h.n_sqz + 3) & ~3;
+  Carver dv;
+  dv.pos = enc_bytes;
+  L.o_z = dv.take(sizeof(float) * (size_t)B * C * F2);
+  L.o_h = dv.take(sizeof(float) * (size_t)B * H * F2);
+  L.o_ac = dv.take(sizeof(float) * (size_t)B * H * F2);
+  L.o_sk = dv.take(sizeof(float) * (size_t)B * H * F2);
+  L.o_nz = dv.take(sizeof(float) * host_noise_floats);
+  L.total = dv.pos;
+  return L;
+}
+
+// The forward pass on worker `w`.  With `final_sync` false the mel object is returned while
+// its last kernels are still queued on w->stream (the fused synthesize path launches the
+// vocoder behind them on the same stream).
+static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const GlowCall& call, int Pmax, bool final_sync,
+                    mi355tts_mel** out) {
+  const mi355tts_glow_hparams& h = gm->hp;
+  const int64_t* ids = call.ids;
+  const int32_t* id_lens = call.id_lens;
+  const int B = call.B, ids_ld = call.ids_ld;
+  const float noise_scale = call.noise_scale, length_scale = call.length_scale;
+  const float* noise = call.noise;
+  const int noise_ld = call.noise_ld;
+  const uint64_t seed = call.seed;
+  const mi355tts_audio_settings* audio = call.audio;
+  const uint32_t flags = call.flags;
   hipStream_t s = w->stream;
   const float* A = gm->arena;
   const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int k = h.kernel_size, nh = h.n_heads;
-  const int P = (Pmax + 3) & ~3;  // row stride
   const bool in_dev = (flags & MI355TTS_IN_DEVICE) != 0;
   const int enc_host_len = B == 1 ? id_lens[0] : -1;
 
   // ---- encoder workspace
-  Carver cv;
-  const size_t o_len = cv.take(sizeof(int) * B);
-  const size_t o_ids = cv.take(sizeof(long long) * (size_t)B * ids_ld);
-  const size_t o_x = cv.take(sizeof(float) * (size_t)B * H * P);
-  const size_t o_t1 = cv.take(sizeof(float) * (size_t)B * H * P);
-  const size_t o_t2 = cv.take(sizeof(float) * (size_t)B * H * P);
-  const size_t o_qkv = cv.take(sizeof(float) * (size_t)B * 3 * H * P);
-  const size_t o_ffn = cv.take(sizeof(float) * (size_t)B * std::max(Fc, 2 * Fd) * P);
-  const size_t o_xm = cv.take(sizeof(float) * (size_t)B * M * P);
-  const size_t o_logw = cv.take(sizeof(float) * (size_t)B * P);
-  const size_t o_cum = cv.take(sizeof(int) * (size_t)B * P);
-  const int att_rows = ((Pmax + ATT_ROWS - 1) / ATT_ROWS) * ATT_ROWS;
-  const size_t o_sc = cv.take(sizeof(float) * (size_t)B * nh * att_rows * P);
-  const size_t enc_bytes = cv.pos;
+  const GlowEncLayout el = glow_enc_layout(h, B, ids_ld, Pmax);
+  const int P = el.P;  // row stride
+  const int att_rows = el.att_rows;
+  const size_t enc_bytes = el.total;
+  const size_t o_len = el.o_len, o_xm = el.o_xm, o_cum = el.o_cum;
   CHECK(reserve(w, enc_bytes));
   char* base = w->arena;
-  int* d_len = (int*)(base + o_len);
-  long long* d_ids = (long long*)(base + o_ids);
-  float* x = (float*)(base + o_x);
-  float* t1 = (float*)(base + o_t1);
-  float* t2 = (float*)(base + o_t2);
-  float* qkv = (float*)(base + o_qkv);
-  float* ffn = (float*)(base + o_ffn);
-  float* xm = (float*)(base + o_xm);
-  float* logw = (float*)(base + o_logw);
-  int* cum = (int*)(base + o_cum);
-  float* sc = (float*)(base + o_sc);
+  int* d_len = (int*)(base + el.o_len);
+  long long* d_ids = (long long*)(base + el.o_ids);
+  float* x = (float*)(base + el.o_x);
+  float* t1 = (float*)(base + el.o_t1);
+  float* t2 = (float*)(base + el.o_t2);
+  float* qkv = (float*)(base + el.o_qkv);
+  float* ffn = (float*)(base + el.o_ffn);
+  float* xm = (float*)(base + el.o_xm);
+  float* logw = (float*)(base + el.o_logw);
+  int* cum = (int*)(base + el.o_cum);
+  float* sc = (float*)(base + el.o_sc);
 
   HIPCHECK(hipMemcpyAsync(d_len, id_lens, sizeof(int) * B, hipMemcpyHostToDevice, s));
   HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
@@ -228,19 +288,14 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   const int C = M * nsq, half = C / 2;
   const int F2max = Fmax / nsq;
   const int F2 = (F2max + 3) & ~3;
-  Carver dv;
-  dv.pos = enc_bytes;
-  const size_t o_z = dv.take(sizeof(float) * (size_t)B * C * F2);
-  const size_t o_h = dv.take(sizeof(float) * (size_t)B * H * F2);
-  const size_t o_ac = dv.take(sizeof(float) * (size_t)B * H * F2);
-  const size_t o_sk = dv.take(sizeof(float) * (size_t)B * H * F2);
-  const size_t o_nz = dv.take((noise && !in_dev) ? sizeof(float) * (size_t)B * M * noise_ld : 0);
-  if (dv.pos > w->arena_bytes) {
+  const GlowDecLayout dl = glow_dec_layout(h, enc_bytes, B, Fmax, (noise && !in_dev) ? (size_t)B * M * noise_ld : 0);
+  const size_t o_z = dl.o_z, o_h = dl.o_h, o_ac = dl.o_ac, o_sk = dl.o_sk, o_nz = dl.o_nz;
+  if (dl.total > w->arena_bytes) {
     // growing would move the encoder buffers: stage the three still-live encoder
     // outputs (x_m, cum, len) through a fresh arena instead
     std::vector<char> keep(enc_bytes);
     HIPCHECK(hipMemcpy(keep.data(), w->arena, enc_bytes, hipMemcpyDeviceToHost));
-    CHECK(reserve(w, dv.pos));
+    CHECK(reserve(w, dl.total));
     HIPCHECK(hipMemcpy(w->arena, keep.data(), enc_bytes, hipMemcpyHostToDevice));
     base = w->arena;
     d_len = (int*)(base + o_len);
@@ -325,9 +380,38 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
     hipLaunchKernelGGL(mel_finalize_kernel, dim3((Fld + 255) / 256, std::min(M, 16), B), dim3(256), 0, s, z, bsZ, F2, d_frames, M,
                        nsq, mel->raw, mel->voc, (long long)M * Fld, Fld, to_mt(audio), audio ? 1 : 0);
   }
-  HIPCHECK(hipStreamSynchronize(s));
-  HIPCHECK(hipGetLastError());
+  if (final_sync) {
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
+  }
   mguard.m = nullptr;
   *out = mel;
   return 0;
+}
+
+extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                   float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                                   const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+  if (!ctx || !out) return fail(MI355TTS_ERR_INVALID, "null argument");
+  const GlowModel* gm = nullptr;
+  CHECK(find_glow(ctx, glow, &gm));
+  GlowCall c;
+  c.ids = ids;
+  c.id_lens = id_lens;
+  c.B = B;
+  c.ids_ld = ids_ld;
+  c.noise_scale = noise_scale;
+  c.length_scale = length_scale;
+  c.noise = noise;
+  c.noise_ld = noise_ld;
+  c.seed = seed;
+  c.audio = audio;
+  c.flags = flags;
+  int Pmax = 0;
+  CHECK(glow_precheck(gm, c, &Pmax));
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  return glow_run(ctx, w, gm, c, Pmax, true, out);
 }

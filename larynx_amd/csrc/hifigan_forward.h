@@ -50,55 +50,117 @@ static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
   return 0;
 }
 
-extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
-                                      float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
-  if (!ctx || !mel) return fail(MI355TTS_ERR_INVALID, "null argument");
-  HifiModel* hm;
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->hifi.find(vocoder);
-    if (it == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no HiFi-GAN model %d", vocoder);
-    hm = it->second.get();
-  }
-  const mi355tts_hifigan_hparams& h = hm->hp;
-  if (mel->M != h.num_mels) return fail(MI355TTS_ERR_INVALID, "mel has %d channels, vocoder expects %d", mel->M, h.num_mels);
-  const int B = mel->B, F = mel->max_frames, hop = hm->hop;
-  const long long N = (long long)F * hop;
-  if (wav_ld < N) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)wav_ld, N);
-  const bool denoise = denoiser_strength > 0.f && F > 0;
-  if (denoise) {
+// One vocoder call's outputs: per row [pad_before zeros][frames[b]*hop samples][zeros up to wav_ld]
+// (the pads are the SSML pauses `_sentence_task` adds with np.pad, larynx/__init__.py:277-283).
+struct VocCall {
+  float denoiser_strength = 0.f;
+  float* wav_f32 = nullptr;
+  int16_t* wav_i16 = nullptr;
+  int64_t wav_ld = 0;
+  uint32_t flags = 0;
+  int pad_before = 0, pad_after = 0;
+};
+
+static int find_hifi(mi355tts_ctx* ctx, int vocoder, HifiModel** out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->hifi.find(vocoder);
+  if (it == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no HiFi-GAN model %d", vocoder);
+  *out = it->second.get();
+  return 0;
+}
+
+// Checks that need no worker (and may run the one-time bias-spectrum pass on a worker of their own).
+static int hifigan_precheck(mi355tts_ctx* ctx, HifiModel* hm, int vocoder, const int32_t* frames, int B, int M, int Fmax,
+                            const VocCall& c) {
+  if (M != hm->hp.num_mels) return fail(MI355TTS_ERR_INVALID, "mel has %d channels, vocoder expects %d", M, hm->hp.num_mels);
+  if (c.pad_before < 0 || c.pad_after < 0) return fail(MI355TTS_ERR_INVALID, "negative pause padding");
+  const long long need = (long long)Fmax * hm->hop + c.pad_before + c.pad_after;
+  if (Fmax >= 0 && c.wav_ld < need) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)c.wav_ld, need);
+  if (c.denoiser_strength > 0.f && Fmax != 0) {
     // the reference's STFT needs more than one 1024-sample frame per utterance
     // (larynx/audio.py:232-249 raises on shorter input)
-    for (int b = 0; b < B; ++b)
-      if ((long long)mel->frames[b] * hop <= DN_FFT)
-        return fail(MI355TTS_ERR_INVALID, "utterance %d has %d frames: too short for the denoiser", b, mel->frames[b]);
+    if (frames)
+      for (int b = 0; b < B; ++b)
+        if ((long long)frames[b] * hm->hop <= DN_FFT)
+          return fail(MI355TTS_ERR_INVALID, "utterance %d has %d frames: too short for the denoiser", b, frames[b]);
     CHECK(ensure_denoiser_bias(ctx, hm, vocoder));
   }
-  const bool out_dev = (flags & MI355TTS_OUT_DEVICE) != 0;
+  return 0;
+}
+
+// Workspace of one vocoder call (bytes, and where each piece sits).  ONE definition, used by the
+// forward pass and by mi355tts_reserve.
+struct HifiLayout {
+  size_t plane = 0, Nld = 0, total = 0;
+  int nbuf = 0, Tmax = 0;
+  size_t o_buf[2 + 4 * 3], o_wav, o_i16, o_peak, o_wav2, o_fbuf;
+};
+static HifiLayout hifi_layout(const mi355tts_hifigan_hparams& h, int hop, int B, int F, bool denoise, bool split_out, int pads) {
+  HifiLayout L;
+  const int C0 = h.upsample_initial_channel;
+  L.plane = (size_t)C0 * (size_t)((F + 3) & ~3);  // row strides are multiples of 4 floats (16-byte staging loads)
+  long long len = F;
+  for (int i = 0; i < h.num_upsamples; ++i) {
+    len *= h.upsample_rates[i];
+    L.plane = std::max(L.plane, (size_t)(C0 >> (i + 1)) * (size_t)((len + 3) & ~3LL));
+  }
+  const long long N = (long long)F * hop;
+  L.Nld = (size_t)((N + 3) & ~3LL);
+  L.nbuf = split_out ? 2 + 4 * h.num_kernels : 6;
+  Carver cv;
+  for (int i = 0; i < L.nbuf; ++i) L.o_buf[i] = cv.take(sizeof(float) * (size_t)B * L.plane);
+  L.o_wav = cv.take(sizeof(float) * (size_t)B * L.Nld);
+  L.o_i16 = cv.take(sizeof(short) * (size_t)B * (L.Nld + (size_t)pads));
+  L.o_peak = cv.take(sizeof(unsigned) * B);
+  L.Tmax = denoise ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0;
+  L.o_wav2 = cv.take(denoise ? sizeof(float) * (size_t)B * L.Nld : 0);
+  L.o_fbuf = cv.take(denoise ? sizeof(float) * (size_t)B * L.Tmax * DN_FFT : 0);
+  L.total = cv.pos;
+  return L;
+}
+static bool hifi_split_out(const mi355tts_ctx* ctx, const mi355tts_hifigan_hparams& h) {
+  return !ctx->serial_branches && h.num_kernels >= 2 && h.num_kernels <= 3;
+}
+
+// The forward pass proper on worker `w` (already checked by hifigan_precheck); ends with the
+// stream synchronised and the outputs delivered.
+static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355tts_mel* mel, const VocCall& call) {
+  const mi355tts_hifigan_hparams& h = hm->hp;
+  const int B = mel->B, F = mel->max_frames, hop = hm->hop;
+  const long long N = (long long)F * hop;
+  const float denoiser_strength = call.denoiser_strength;
+  float* const wav_f32 = call.wav_f32;
+  int16_t* const wav_i16 = call.wav_i16;
+  const int64_t wav_ld = call.wav_ld;
+  const bool denoise = denoiser_strength > 0.f && F > 0;
+  const bool out_dev = (call.flags & MI355TTS_OUT_DEVICE) != 0;
+  const int pad0 = call.pad_before;
+  hipStream_t s = w->stream;
   if (F == 0) {
-    if (!out_dev) {
+    if (out_dev) {
+      if (wav_f32) HIPCHECK(hipMemsetAsync(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld, s));
+      if (wav_i16) HIPCHECK(hipMemsetAsync(wav_i16, 0, sizeof(int16_t) * (size_t)B * wav_ld, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    } else {
       if (wav_f32) std::memset(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld);
       if (wav_i16) std::memset(wav_i16, 0, sizeof(int16_t) * (size_t)B * wav_ld);
     }
     return 0;
   }
-  HIPCHECK(hipSetDevice(ctx->device));
-  Worker* w = nullptr;
-  CHECK(acquire_worker(ctx, &w));
-  WorkerGuard guard{ctx, w};
-  hipStream_t s = w->stream;
-  const int C0 = h.upsample_initial_channel;
-  // largest [C][L] plane over conv_pre and the stages
-  const int Fp = (F + 3) & ~3;  // row strides are multiples of 4 floats (16-byte staging loads)
-  size_t plane = (size_t)C0 * Fp;
-  {
-    long long L = F;
-    for (int i = 0; i < h.num_upsamples; ++i) {
-      L *= h.upsample_rates[i];
-      plane = std::max(plane, (size_t)(C0 >> (i + 1)) * (size_t)L);
+  // an error return after kernels were queued must not hand the worker (its arena!) to the
+  // next call while they still run — possibly on the side streams
+  struct DrainOnError {
+    Worker* w;
+    bool ok = false;
+    ~DrainOnError() {
+      if (ok) return;
+      hipStreamSynchronize(w->stream);
+      for (int i = 0; i < 2; ++i)
+        if (w->aux[i]) hipStreamSynchronize(w->aux[i]);
     }
-  }
-  const size_t Nld = (size_t)((N + 3) & ~3LL);
+  } drain{w};
+  const int C0 = h.upsample_initial_channel;
+  const int Fp = (F + 3) & ~3;
   const int nk = h.num_kernels;
   // The nk ResBlock chains of a stage are independent (MRF).  Each chain writes its own
   // output and the average is taken by the consumer's staging load (`split_out`).  A call
@@ -110,7 +172,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   // same values in the same order: results do not depend on the load.
   // `serial_branches` (profiling / tests) additionally folds the average into the chains'
   // last epilogues (in-place accumulation, one output buffer).
-  const bool split_out = !ctx->serial_branches && nk >= 2 && nk <= 3;
+  const bool split_out = hifi_split_out(ctx, h);
   const bool concurrent = split_out && !(ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1);
   if (concurrent && !w->aux[0]) {
     for (int i = 0; i < 2; ++i) {
@@ -126,23 +188,18 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
   static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
   const int rb_tiles = rb_env > 0 ? rb_env : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
-  const int nbuf = split_out ? 2 + 4 * nk : 6;
-  Carver cv;
-  size_t o_buf[16];
-  for (int i = 0; i < nbuf; ++i) o_buf[i] = cv.take(sizeof(float) * (size_t)B * plane);
-  const size_t o_wav = cv.take(sizeof(float) * (size_t)B * Nld);
-  const size_t o_i16 = cv.take(sizeof(short) * (size_t)B * Nld);
-  const size_t o_peak = cv.take(sizeof(unsigned) * B);
-  const int Tmax = denoise ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0;
-  const size_t o_wav2 = cv.take(denoise ? sizeof(float) * (size_t)B * Nld : 0);
-  const size_t o_fbuf = cv.take(denoise ? sizeof(float) * (size_t)B * Tmax * DN_FFT : 0);
-  CHECK(reserve(w, cv.pos));
+  const int pads = call.pad_before + call.pad_after;
+  const HifiLayout lay = hifi_layout(h, hop, B, F, denoise, split_out, pads);
+  const size_t Nld = lay.Nld;
+  const int nbuf = lay.nbuf, Tmax = lay.Tmax;
+  CHECK(reserve(w, lay.total));
   char* base = w->arena;
-  float* buf[16];
-  for (int i = 0; i < nbuf; ++i) buf[i] = (float*)(base + o_buf[i]);
-  float* wav = (float*)(base + o_wav);
-  short* i16 = (short*)(base + o_i16);
-  unsigned* peak = (unsigned*)(base + o_peak);
+  float* buf[2 + 4 * 3];
+  for (int i = 0; i < nbuf; ++i) buf[i] = (float*)(base + lay.o_buf[i]);
+  float* wav = (float*)(base + lay.o_wav);
+  short* i16 = (short*)(base + lay.o_i16);
+  unsigned* peak = (unsigned*)(base + lay.o_peak);
+  const size_t o_wav2 = lay.o_wav2, o_fbuf = lay.o_fbuf;
   const int* d_frames = mel->frames_dev;
 
   // stage input: `cur[0]` alone, or the nk chain outputs cur[0..nk) still to be averaged
@@ -169,8 +226,9 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     const int u = h.upsample_rates[i], ku = h.upsample_kernel_sizes[i];
     const int cout = C0 >> (i + 1);
     const int Lout = Lin * u;
+    const int ldo = (Lout + 3) & ~3;  // row stride of this stage's planes (16-byte staging loads)
     {  // x = ups[i](leaky_relu(x, 0.1))  (models.py:189-190)
-      ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, xu, (long long)cout * Lout, Lout, d_frames, mul * u, 1, ku / u - 1);
+      ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, xu, (long long)cout * ldo, ldo, d_frames, mul * u, 1, ku / u - 1);
       set_inputs(a);
       a.in_slope = 0.1f;
       a.up = u;
@@ -179,13 +237,13 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
     }
     mul *= u;
     ch = cout;
-    const long long bs = (long long)ch * Lout;
+    const long long bs = (long long)ch * ldo;
     const float inv_nk = 1.0f / (float)nk;
     if (concurrent) {
       HIPCHECK(hipEventRecord(w->ev_fork, s));
       for (int j = 1; j < nk; ++j) HIPCHECK(hipStreamWaitEvent(w->aux[j - 1], w->ev_fork, 0));
     }
-    float* outs[3] = {nullptr, nullptr, nullptr};
+    float* outs[MI355TTS_MAX_STAGES] = {nullptr};
     for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
       const int kk = h.resblock_kernel_sizes[j];
       hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
@@ -213,17 +271,17 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           {
             const float pa_alpha = (last && !split_out) ? inv_nk : 1.0f;
             const int pa_accum = (last && !split_out) ? (j > 0) : 0;
-            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, Lout, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
+            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, ldo, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
             if (fr < 0) return fr;
             if (fr == 0) {
               rin = dst;
               continue;
             }
           }
-          ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, tb, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+          ConvArgs a = base_args(rin, bs, ldo, d_frames, mul, tb, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
           CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
-          ConvArgs c = base_args(tb, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, 1, (kk - 1) / 2);
+          ConvArgs c = base_args(tb, bs, ldo, d_frames, mul, dst, bs, ldo, d_frames, mul, 1, (kk - 1) / 2);
           c.in_slope = 0.1f;
           c.res = rin;
           if (last && !split_out) {
@@ -232,7 +290,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
           }
           CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
         } else {  // ResBlock2.forward, models.py:136-141
-          ConvArgs a = base_args(rin, bs, Lout, d_frames, mul, dst, bs, Lout, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+          ConvArgs a = base_args(rin, bs, ldo, d_frames, mul, dst, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
           a.in_slope = 0.1f;
           a.res = rin;
           if (last && !split_out) {
@@ -261,7 +319,7 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
       ncur = 1;
     }
     Lin = Lout;
-    ldin = Lout;
+    ldin = ldo;
   }
   {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
     ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
@@ -280,6 +338,8 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
                        (long long)Nld);
     wav = wav2;
   }
+  const size_t ild = Nld + (size_t)pads;  // row stride of the int16 staging buffer
+  const long long rowlen = (long long)pad0 + N + call.pad_after;  // samples delivered per row (then zeros up to wav_ld)
   {
     ProfScope ps(ctx, w, KC_SMALL, 0);
     hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
@@ -287,31 +347,91 @@ extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi35
       HIPCHECK(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
       hipLaunchKernelGGL(absmax_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak);
       hipLaunchKernelGGL(to_int16_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak, i16,
-                         (long long)Nld, (long long)Nld);
+                         (long long)ild, (long long)ild, pad0);
     }
   }
-  const hipMemcpyKind kind = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (out_dev) {
+    for (int b = 0; b < B; ++b) {
+      if (wav_f32) {
+        float* dst = wav_f32 + (size_t)b * wav_ld;
+        if (pad0) HIPCHECK(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)pad0, s));
+        HIPCHECK(hipMemcpyAsync(dst + pad0, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, s));
+        if (wav_ld > pad0 + N) HIPCHECK(hipMemsetAsync(dst + pad0 + N, 0, sizeof(float) * (size_t)(wav_ld - pad0 - N), s));
+      }
+      if (wav_i16) {
+        int16_t* dst = wav_i16 + (size_t)b * wav_ld;
+        HIPCHECK(hipMemcpyAsync(dst, i16 + (size_t)b * ild, sizeof(short) * (size_t)rowlen, hipMemcpyDeviceToDevice, s));
+        if (wav_ld > rowlen) HIPCHECK(hipMemsetAsync(dst + rowlen, 0, sizeof(short) * (size_t)(wav_ld - rowlen), s));
+      }
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
+    drain.ok = true;
+    return 0;
+  }
+  // host outputs: device -> the worker's pinned staging (async DMA) -> the caller's (pageable)
+  // buffers; a pageable destination would make every hipMemcpyAsync a blocking staged copy
+  const size_t f32_bytes = wav_f32 ? sizeof(float) * (size_t)B * (size_t)N : 0;
+  const size_t i16_bytes = wav_i16 ? sizeof(short) * (size_t)B * (size_t)rowlen : 0;
+  CHECK(reserve_pinned_out(w, f32_bytes + i16_bytes));
+  float* pf = (float*)w->pinned_out;
+  short* pi = (short*)(w->pinned_out + f32_bytes);
   for (int b = 0; b < B; ++b) {
-    if (wav_f32) {
-      HIPCHECK(hipMemcpyAsync(wav_f32 + (size_t)b * wav_ld, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, kind, s));
-      if (wav_ld > N) {
-        if (out_dev) HIPCHECK(hipMemsetAsync(wav_f32 + (size_t)b * wav_ld + N, 0, sizeof(float) * (size_t)(wav_ld - N), s));
-      }
-    }
-    if (wav_i16) {
-      HIPCHECK(hipMemcpyAsync(wav_i16 + (size_t)b * wav_ld, i16 + (size_t)b * Nld, sizeof(short) * (size_t)N, kind, s));
-      if (wav_ld > N) {
-        if (out_dev) HIPCHECK(hipMemsetAsync(wav_i16 + (size_t)b * wav_ld + N, 0, sizeof(short) * (size_t)(wav_ld - N), s));
-      }
-    }
+    if (wav_f32) HIPCHECK(hipMemcpyAsync(pf + (size_t)b * N, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, s));
+    if (wav_i16) HIPCHECK(hipMemcpyAsync(pi + (size_t)b * rowlen, i16 + (size_t)b * ild, sizeof(short) * (size_t)rowlen, hipMemcpyDeviceToHost, s));
   }
   HIPCHECK(hipStreamSynchronize(s));
   HIPCHECK(hipGetLastError());
-  if (!out_dev && wav_ld > N) {
-    for (int b = 0; b < B; ++b) {
-      if (wav_f32) std::memset(wav_f32 + (size_t)b * wav_ld + N, 0, sizeof(float) * (size_t)(wav_ld - N));
-      if (wav_i16) std::memset(wav_i16 + (size_t)b * wav_ld + N, 0, sizeof(int16_t) * (size_t)(wav_ld - N));
+  drain.ok = true;
+  for (int b = 0; b < B; ++b) {
+    if (wav_f32) {
+      float* dst = wav_f32 + (size_t)b * wav_ld;
+      std::memset(dst, 0, sizeof(float) * (size_t)pad0);
+      std::memcpy(dst + pad0, pf + (size_t)b * N, sizeof(float) * (size_t)N);
+      std::memset(dst + pad0 + N, 0, sizeof(float) * (size_t)(wav_ld - pad0 - N));
+    }
+    if (wav_i16) {
+      int16_t* dst = wav_i16 + (size_t)b * wav_ld;
+      std::memcpy(dst, pi + (size_t)b * rowlen, sizeof(short) * (size_t)rowlen);
+      std::memset(dst + rowlen, 0, sizeof(int16_t) * (size_t)(wav_ld - rowlen));
     }
   }
   return 0;
+}
+
+static int hifigan_call(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, const VocCall& call) {
+  if (!ctx || !mel) return fail(MI355TTS_ERR_INVALID, "null argument");
+  HifiModel* hm = nullptr;
+  CHECK(find_hifi(ctx, vocoder, &hm));
+  CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), mel->B, mel->M, mel->max_frames, call));
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  return hifigan_run(ctx, w, hm, mel, call);
+}
+
+extern "C" int mi355tts_hifigan_infer(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                                      float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
+  VocCall c;
+  c.denoiser_strength = denoiser_strength;
+  c.wav_f32 = wav_f32;
+  c.wav_i16 = wav_i16;
+  c.wav_ld = wav_ld;
+  c.flags = flags;
+  return hifigan_call(ctx, vocoder, mel, c);
+}
+
+extern "C" int mi355tts_hifigan_infer_padded(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, float denoiser_strength,
+                                             float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags,
+                                             int32_t pad_before, int32_t pad_after) {
+  VocCall c;
+  c.denoiser_strength = denoiser_strength;
+  c.wav_f32 = wav_f32;
+  c.wav_i16 = wav_i16;
+  c.wav_ld = wav_ld;
+  c.flags = flags;
+  c.pad_before = pad_before;
+  c.pad_after = pad_after;
+  return hifigan_call(ctx, vocoder, mel, c);
 }

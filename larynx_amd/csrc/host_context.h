@@ -20,6 +20,8 @@ struct Worker {
   size_t arena_pos = 0;
   int* pinned = nullptr;  // pinned host staging for frame counts
   size_t pinned_ints = 0;
+  char* pinned_out = nullptr;  // pinned host staging for waveform outputs (grow-only)
+  size_t pinned_out_bytes = 0;
   std::vector<ProfEvent> events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   // side streams for the independent MRF branches of a HiFi-GAN stage
@@ -45,6 +47,7 @@ struct mi355tts_ctx {
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;
+  std::map<void*, size_t> mel_sizes;  // true size of every block the pool has ever handed out
   struct Acc {
     long long launches = 0;
     double ms = 0, flop = 0;
@@ -139,6 +142,19 @@ static int reserve(Worker* w, size_t bytes) {
   hipError_t e = hipMalloc(&w->arena, want);
   if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc(%zu) for workspace: %s", want, hipGetErrorString(e));
   w->arena_bytes = want;
+  return 0;
+}
+static int reserve_pinned_out(Worker* w, size_t bytes) {
+  if (bytes <= w->pinned_out_bytes) return 0;
+  if (w->pinned_out) {
+    HIPCHECK(hipHostFree(w->pinned_out));
+    w->pinned_out = nullptr;
+    w->pinned_out_bytes = 0;
+  }
+  const size_t want = bytes + bytes / 4 + (1 << 16);
+  hipError_t e = hipHostMalloc(&w->pinned_out, want, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipHostMalloc(%zu) for output staging: %s", want, hipGetErrorString(e));
+  w->pinned_out_bytes = want;
   return 0;
 }
 struct Carver {

@@ -69,6 +69,7 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
     if (w->ev_fork) hipEventDestroy(w->ev_fork);
     if (w->arena) hipFree(w->arena);
     if (w->pinned) hipHostFree(w->pinned);
+    if (w->pinned_out) hipHostFree(w->pinned_out);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
   }
@@ -96,9 +97,12 @@ static int check_glow_hp(const mi355tts_glow_hparams* h) {
     return fail(MI355TTS_ERR_INVALID, "hidden_channels %d must be a multiple of 32", h->hidden_channels);
   if (h->hidden_channels / h->n_heads > ATT_MAXDK) return fail(MI355TTS_ERR_INVALID, "head dim > %d unsupported", ATT_MAXDK);
   if (2 * h->window_size + 1 > ATT_MAXW) return fail(MI355TTS_ERR_INVALID, "window_size too large");
-  if (h->n_split > 8 || h->n_split % 2 || (h->mel_channels * h->n_sqz) % h->n_split)
+  if (h->mel_channels < 1 || h->n_sqz < 1 || ((h->mel_channels * h->n_sqz) & 1)) return fail(MI355TTS_ERR_INVALID, "bad n_sqz");
+  if (h->n_split < 2 || h->n_split > 8 || h->n_split % 2 || (h->mel_channels * h->n_sqz) % h->n_split)
     return fail(MI355TTS_ERR_INVALID, "bad n_split");
-  if (h->n_sqz < 1 || ((h->mel_channels * h->n_sqz) & 1)) return fail(MI355TTS_ERR_INVALID, "bad n_sqz");
+  if (h->n_blocks_dec < 0 || h->n_layers_enc < 0 || h->n_block_layers < 1 || h->filter_channels < 1 || h->filter_channels_dp < 1 ||
+      h->dilation_rate < 1 || h->window_size < 0)
+    return fail(MI355TTS_ERR_INVALID, "bad GlowTTS hparams");
   if (h->kernel_size != 1 && h->kernel_size != 3 && h->kernel_size != 5) return fail(MI355TTS_ERR_INVALID, "bad kernel_size");
   if (h->kernel_size_dec != 3 && h->kernel_size_dec != 5) return fail(MI355TTS_ERR_INVALID, "bad kernel_size_dec");
   return 0;
@@ -434,15 +438,20 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
 }
 
 // ------------------------------------------------------------------ mel objects
+// Recycled device blocks for the result objects.  Small blocks (frame counts) are one 4 KB
+// class; larger ones are handed out best-fit with no upper bound on the slack (HBM is not the
+// scarce resource here — a hipMalloc, which synchronises the device under concurrent calls, is).
+static size_t pool_round(size_t bytes) { return bytes <= 4096 ? 4096 : ((bytes + 65535) & ~(size_t)65535); }
 static void* pool_alloc(mi355tts_ctx* ctx, size_t bytes) {
-  bytes = (bytes + 4095) & ~(size_t)4095;
+  bytes = pool_round(bytes);
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     int best = -1;
-    for (int i = 0; i < (int)ctx->mel_pool.size(); ++i)
-      if (ctx->mel_pool[i].second >= bytes && ctx->mel_pool[i].second <= 2 * bytes + (1 << 16) &&
-          (best < 0 || ctx->mel_pool[i].second < ctx->mel_pool[best].second))
-        best = i;
+    for (int i = 0; i < (int)ctx->mel_pool.size(); ++i) {
+      const size_t have = ctx->mel_pool[i].second;
+      if (have < bytes || (bytes == 4096) != (have == 4096)) continue;
+      if (best < 0 || have < ctx->mel_pool[best].second) best = i;
+    }
     if (best >= 0) {
       void* p = ctx->mel_pool[best].first;
       ctx->mel_pool.erase(ctx->mel_pool.begin() + best);
@@ -450,19 +459,20 @@ static void* pool_alloc(mi355tts_ctx* ctx, size_t bytes) {
     }
   }
   void* p = nullptr;
-  // the block remembers its size in the pool entry when it comes back; keep a header-free
-  // scheme by rounding deterministically (see pool_free)
   if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->mel_sizes[p] = bytes;
   return p;
 }
-static void pool_free(mi355tts_ctx* ctx, void* p, size_t bytes) {
+static void pool_free(mi355tts_ctx* ctx, void* p, size_t /*requested*/) {
   if (!p) return;
-  bytes = (bytes + 4095) & ~(size_t)4095;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (ctx->mel_pool.size() < 96) {
+  const size_t bytes = ctx->mel_sizes[p];  // the block's true size, not the size last asked for
+  if (ctx->mel_pool.size() < 256) {
     ctx->mel_pool.emplace_back(p, bytes);
     return;
   }
+  ctx->mel_sizes.erase(p);
   hipFree(p);
 }
 static size_t mel_bytes(const mi355tts_mel* m) { return (size_t)m->B * m->M * (size_t)std::max(m->ld, 1) * sizeof(float); }
@@ -563,6 +573,136 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
 
 #include "glow_forward.h"
 #include "hifigan_forward.h"
+
+// ------------------------------------------------------------------ fused call + reservation
+// ids -> int16/f32 waveform in ONE call on ONE worker: GlowTTS and the vocoder are queued
+// back to back on the same stream, so the only host synchronisations are the frame-count
+// read-back and the final one (the two-call form adds a sync, a worker hand-over and a mel
+// object round trip through the caller).  Replaces the body of `_sentence_task`
+// (larynx/__init__.py:229-283) between the two log lines, pause padding included.
+extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
+                                   int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld,
+                                   uint64_t seed, const mi355tts_audio_settings* audio, float denoiser_strength,
+                                   int32_t pad_before, int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16,
+                                   int64_t wav_ld, uint32_t flags) {
+  if (!ctx || !frames_out) return fail(MI355TTS_ERR_INVALID, "null argument");
+  const GlowModel* gm = nullptr;
+  HifiModel* hm = nullptr;
+  CHECK(find_glow(ctx, glow, &gm));
+  CHECK(find_hifi(ctx, vocoder, &hm));
+  GlowCall g;
+  g.ids = ids;
+  g.id_lens = id_lens;
+  g.B = B;
+  g.ids_ld = ids_ld;
+  g.noise_scale = noise_scale;
+  g.length_scale = length_scale;
+  g.noise = noise;
+  g.noise_ld = noise_ld;
+  g.seed = seed;
+  g.audio = audio;
+  g.flags = flags & MI355TTS_IN_DEVICE;
+  VocCall v;
+  v.denoiser_strength = denoiser_strength;
+  v.wav_f32 = wav_f32;
+  v.wav_i16 = wav_i16;
+  v.wav_ld = wav_ld;
+  v.flags = flags & MI355TTS_OUT_DEVICE;
+  v.pad_before = pad_before;
+  v.pad_after = pad_after;
+  int Pmax = 0;
+  CHECK(glow_precheck(gm, g, &Pmax));
+  CHECK(hifigan_precheck(ctx, hm, vocoder, nullptr, B, gm->hp.mel_channels, -1, v));  // incl. the one-time denoiser bias
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  mi355tts_mel* mel = nullptr;
+  CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
+  struct MelDrop {
+    Worker* w;
+    mi355tts_mel* m;
+    ~MelDrop() {
+      hipStreamSynchronize(w->stream);  // its blocks go back to the pool: nothing queued may still read them
+      mel_destroy(m);
+    }
+  } drop{w, mel};
+  for (int b = 0; b < B; ++b) frames_out[b] = mel->frames[b];
+  CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), B, mel->M, mel->max_frames, v));
+  return hifigan_run(ctx, w, hm, mel, v);
+}
+
+// Pre-create `workers` workers (streams, pinned staging, side streams) and size their
+// workspaces and the result-block pool for calls of up to `max_batch` rows x `max_ids`
+// ids x `max_frames` frames, so that steady-state calls never hipMalloc / hipFree (both
+// synchronise the whole device and stall every other in-flight call).
+extern "C" int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vocoder, int max_batch, int max_ids,
+                                int max_frames, int denoiser, int max_pad_samples) {
+  if (!ctx || workers < 1 || workers > 256 || max_batch < 1 || max_ids < 1 || max_frames < 1 || max_pad_samples < 0)
+    return fail(MI355TTS_ERR_INVALID, "bad argument");
+  const GlowModel* gm = nullptr;
+  HifiModel* hm = nullptr;
+  if (glow > 0) CHECK(find_glow(ctx, glow, &gm));
+  if (vocoder > 0) CHECK(find_hifi(ctx, vocoder, &hm));
+  if (gm && max_frames % gm->hp.n_sqz) max_frames += gm->hp.n_sqz - max_frames % gm->hp.n_sqz;
+  size_t need = 0, mel_bytes = 0;
+  int M = 0;
+  if (gm) {
+    const GlowEncLayout el = glow_enc_layout(gm->hp, max_batch, max_ids, max_ids);
+    const GlowDecLayout dl = glow_dec_layout(gm->hp, el.total, max_batch, max_frames, 0);
+    need = std::max(need, dl.total);
+    M = gm->hp.mel_channels;
+  }
+  size_t out_bytes = 0;
+  if (hm) {
+    const bool dn = denoiser != 0 && (long long)max_frames * hm->hop > DN_FFT;
+    // both vocoder schedules (forked MRF chains / one stream) carve the same planes unless serial_branches is set
+    const HifiLayout a = hifi_layout(hm->hp, hm->hop, max_batch, max_frames, dn, true && hm->hp.num_kernels >= 2 && hm->hp.num_kernels <= 3, max_pad_samples);
+    const HifiLayout b = hifi_layout(hm->hp, hm->hop, max_batch, max_frames, dn, false, max_pad_samples);
+    need = std::max(need, std::max(a.total, b.total));
+    M = std::max(M, (int)hm->hp.num_mels);
+    out_bytes = (size_t)max_batch * ((size_t)max_frames * hm->hop + max_pad_samples) * (sizeof(float) + sizeof(short));
+    if (dn) CHECK(ensure_denoiser_bias(ctx, hm, vocoder));
+  }
+  mel_bytes = (size_t)max_batch * M * (size_t)((max_frames + 3) & ~3) * sizeof(float);
+  HIPCHECK(hipSetDevice(ctx->device));
+  std::vector<Worker*> held;
+  int rc = 0;
+  for (int i = 0; i < workers && !rc; ++i) {
+    Worker* w = nullptr;
+    rc = acquire_worker(ctx, &w);  // holding them all forces `workers` distinct objects
+    if (rc) break;
+    held.push_back(w);
+    rc = reserve(w, need);
+    if (!rc) rc = reserve_pinned_out(w, out_bytes);
+    if (!rc && hm && !w->aux[0]) {
+      for (int k = 0; k < 2 && !rc; ++k) {
+        if (hipStreamCreateWithFlags(&w->aux[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&w->ev_join[k], hipEventDisableTiming) != hipSuccess)
+          rc = fail(MI355TTS_ERR_HIP, "side stream creation failed");
+      }
+      if (!rc && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "event creation failed");
+    }
+  }
+  for (Worker* w : held) release_worker(ctx, w);
+  if (rc) return rc;
+  // result blocks: per in-flight call two mel planes + one frame-count block
+  if (mel_bytes) {
+    std::vector<void*> blocks;
+    for (int i = 0; i < workers && !rc; ++i) {
+      for (int k = 0; k < 2; ++k) {
+        void* p = pool_alloc(ctx, mel_bytes);
+        if (!p) rc = fail(MI355TTS_ERR_NOMEM, "hipMalloc result block");
+        else blocks.push_back(p);
+      }
+      void* q = pool_alloc(ctx, sizeof(int) * (size_t)max_batch);
+      if (!q) rc = fail(MI355TTS_ERR_NOMEM, "hipMalloc result block");
+      else blocks.push_back(q);
+    }
+    for (void* p : blocks) pool_free(ctx, p, 0);
+  }
+  return rc;
+}
 
 // ------------------------------------------------------------------ single operators
 static int op_conv_common(mi355tts_ctx* ctx, const float* x, int B, int Cin, int L, const int32_t* lens, const float* wt,
@@ -675,6 +815,22 @@ extern "C" int mi355tts_op_denoise(mi355tts_ctx* ctx, const float* wav, int B, i
   hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fb, T, dfr, DN_HOP, dout, (long long)N, (long long)N);
   HIPCHECK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)B * N, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi355tts_op_gauss_noise(mi355tts_ctx* ctx, uint64_t seed, int B, int C, int T, float* out) {
+  if (!ctx || !out || B <= 0 || C <= 0 || T <= 0 || C > 65535 || B > 65535) return fail(MI355TTS_ERR_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  const size_t n = (size_t)B * C * T;
+  CHECK(reserve(w, n * sizeof(float)));
+  float* d = (float*)w->arena;
+  hipLaunchKernelGGL(noise_fill_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, w->stream, d, C, T, seed);
+  HIPCHECK(hipMemcpyAsync(out, d, n * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  HIPCHECK(hipStreamSynchronize(w->stream));
   HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -421,19 +421,40 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
 // (glow_tts/models.py:323-336).  One workgroup per batch row.
 __global__ void duration_kernel(const float* logw, long long bs, const int* len, float length_scale, int n_sqz,
                                 int* cum, int cum_ld, int* frames, int max_frames_cap) {
+  // one wave per row: lane l owns the contiguous run [l*per, (l+1)*per) of ids, sums its
+  // durations, the 64 run totals are scanned with __shfl_up, and the run is walked a second
+  // time to write the inclusive cumsum.  Durations are integers (ceil), so the int sum equals
+  // the reference's float cumsum exactly; one duration is capped at max_frames_cap (exp overflow).
   const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x >= 64) return;
   const int P = len[b];
-  float total = 0.f;
-  for (int t = 0; t < P; ++t) {
-    const float w = expf(logw[(long long)b * bs + t]) * length_scale;
-    total += ceilf(w);
-    cum[(long long)b * cum_ld + t] = (int)total;
+  const int per = (P + 63) / 64;
+  const int t0 = lane * per;
+  const int t1 = t0 + per < P ? t0 + per : P;
+  const float* lw = logw + (long long)b * bs;
+  const float capf = (float)max_frames_cap;  // <= 2^28: two capped terms still fit an int
+  auto dur = [&](int t) { return (int)fminf(fmaxf(ceilf(expf(lw[t]) * length_scale), 0.f), capf); };
+  int run = 0;
+  for (int t = t0; t < t1; ++t) run = min(run + dur(t), max_frames_cap);
+  int incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl = min(incl + o, max_frames_cap);
   }
-  int y = (int)fmaxf(total, 1.0f);
-  y = (y / n_sqz) * n_sqz;
-  if (y > max_frames_cap) y = (max_frames_cap / n_sqz) * n_sqz;
-  frames[b] = y;
+  int acc = incl - run;  // exclusive prefix of this lane's run
+  for (int t = t0; t < t1; ++t) {
+    acc = min(acc + dur(t), max_frames_cap);
+    cum[(long long)b * cum_ld + t] = acc;
+  }
+  const int total = __shfl(incl, 63);
+  if (lane == 0) {
+    int y = total > 1 ? total : 1;
+    y = (y / n_sqz) * n_sqz;
+    if (y > max_frames_cap) y = (max_frames_cap / n_sqz) * n_sqz;
+    frames[b] = y;
+  }
 }
 
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
@@ -449,6 +470,13 @@ __device__ __forceinline__ float gauss_noise(uint64_t seed, uint32_t b, uint32_t
   const float u1 = ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
   const float u2 = (float)(y >> 8) * (1.0f / 16777216.0f);
   return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+
+// The generator alone, out[b][c][t] = gauss_noise(seed, b, c, t): what the distribution tests look at.
+__global__ void noise_fill_kernel(float* out, int C, int T, uint64_t seed) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T) out[((long long)b * C + c) * T + t] = gauss_noise(seed, (uint32_t)b, (uint32_t)c, (uint32_t)t);
 }
 
 // G9b+G10+G11: frame j of row b repeats id idx(j) = #{t : cum[t] <= j}
@@ -588,15 +616,19 @@ __global__ void absmax_kernel(const float* wav, long long bs, const int* frames,
 // H5 pass 2: `audio_float_to_int16` (larynx/audio.py:118-125): a * 32767/max(0.01,peak),
 // clip, truncate toward zero; the padded tail is zero.
 __global__ void to_int16_kernel(const float* wav, long long bs, const int* frames, int hop, const unsigned* peak_bits,
-                                short* out, long long out_bs, long long out_ld) {
+                                short* out, long long out_bs, long long out_ld, int pad_before) {
+  // `pad_before` zero samples precede the audio in the output row (SSML <break> before the
+  // sentence, larynx/__init__.py:277-283); everything past the audio up to out_ld is zero
+  // too, which covers the pause after the sentence.
   const int b = blockIdx.y;
   const long long N = (long long)frames[b] * hop;
   const float peak = fmaxf(0.01f, __uint_as_float(peak_bits[b]));
   const float g = 32767.0f / peak;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < out_ld; i += (long long)gridDim.x * blockDim.x) {
     short s = 0;
-    if (i < N) {
-      float v = wav[(long long)b * bs + i] * g;
+    const long long j = i - pad_before;
+    if (j >= 0 && j < N) {
+      float v = wav[(long long)b * bs + j] * g;
       v = fminf(fmaxf(v, -32767.0f), 32767.0f);
       s = (short)(int)v;
     }

@@ -188,9 +188,77 @@ class Engine:
         )
         return MelBatch(self, out.value)
 
-    def hifigan_infer_raw(self, vocoder, mel: MelBatch, f32_ptr, i16_ptr, wav_ld, flags=0, denoiser_strength=0.0):
-        ffi.check(self.lib, self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, float(denoiser_strength), f32_ptr,
-                                                           i16_ptr, wav_ld, flags))
+    def hifigan_infer_raw(self, vocoder, mel: MelBatch, f32_ptr, i16_ptr, wav_ld, flags=0, denoiser_strength=0.0,
+                          pad_before=0, pad_after=0):
+        ffi.check(self.lib, self.lib.mi355tts_hifigan_infer_padded(self._ctx, vocoder, mel.handle, float(denoiser_strength),
+                                                                  f32_ptr, i16_ptr, wav_ld, flags, int(pad_before), int(pad_after)))
+
+    def synthesize_raw(self, glow, vocoder, ids_ptr, lens, ids_ld, noise_scale, length_scale, f32_ptr, i16_ptr, wav_ld,
+                       noise_ptr=None, noise_ld=0, seed=0, audio_settings=None, denoiser_strength=0.0, pad_before=0,
+                       pad_after=0, flags=0) -> np.ndarray:
+        """Pointer-level fused call (`mi355tts_synthesize`); returns the per-row mel frame counts."""
+        lens = np.ascontiguousarray(lens, np.int32)
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        frames = np.zeros(len(lens), np.int32)
+        ffi.check(
+            self.lib,
+            self.lib.mi355tts_synthesize(
+                self._ctx, glow, vocoder, ids_ptr, lens.ctypes.data_as(C.POINTER(C.c_int32)), len(lens), ids_ld,
+                float(noise_scale), float(length_scale), noise_ptr, noise_ld, int(seed) & (2 ** 64 - 1),
+                C.byref(a) if a is not None else None, float(denoiser_strength), int(pad_before), int(pad_after),
+                frames.ctypes.data_as(C.POINTER(C.c_int32)), f32_ptr, i16_ptr, wav_ld, flags,
+            ),
+        )
+        return frames
+
+    def synthesize(self, glow: int, vocoder: int, ids, noise_scale: float = 0.667, length_scale: float = 1.0,
+                   noise: typing.Optional[np.ndarray] = None, seed: int = 0, audio_settings=None,
+                   denoiser_strength: float = 0.0, pad_before: int = 0, pad_after: int = 0, want_float: bool = False,
+                   frames_per_id_guess: float = 8.0):
+        """ids -> (frames [B], wav_f32 [B, n] or None, wav_i16 [B, n]) through ONE fused call
+        (`mi355tts_synthesize`): row b holds pad_before zeros, frames[b]*hop samples, then zeros.
+        The frame count is data dependent; the output buffer is sized from a guess and the call
+        is repeated once with the exact size in the rare case the guess was too small."""
+        rows = [np.asarray(ids, np.int64)] if isinstance(ids, np.ndarray) and ids.ndim == 1 else [np.asarray(r, np.int64) for r in ids]
+        B = len(rows)
+        lens = np.array([len(r) for r in rows], np.int32)
+        ld = int(lens.max())
+        packed = np.zeros((B, ld), np.int64)
+        for b, r in enumerate(rows):
+            packed[b, : len(r)] = r
+        nz_ptr, nz_ld = None, 0
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float32)
+            if noise.ndim == 2:
+                noise = noise[None]
+            nz_ptr, nz_ld = noise.ctypes.data, noise.shape[2]
+        hop = self.hop(vocoder)
+        pads = int(pad_before) + int(pad_after)
+        cap = int(ld * frames_per_id_guess * max(length_scale, 0.05)) * hop + pads
+        lens_c = lens.ctypes.data_as(C.POINTER(C.c_int32))
+        a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
+        frames = np.zeros(B, np.int32)
+        for attempt in range(2):
+            f32 = np.empty((B, cap), np.float32) if want_float else None
+            i16 = np.empty((B, cap), np.int16)
+            rc = self.lib.mi355tts_synthesize(
+                self._ctx, glow, vocoder, packed.ctypes.data, lens_c, B, ld, float(noise_scale), float(length_scale), nz_ptr,
+                nz_ld, int(seed) & (2 ** 64 - 1), C.byref(a) if a is not None else None, float(denoiser_strength),
+                int(pad_before), int(pad_after), frames.ctypes.data_as(C.POINTER(C.c_int32)), ffi.ptr(f32), i16.ctypes.data, cap, 0,
+            )
+            n = int(frames.max()) * hop + pads
+            if rc == -4 and attempt == 0 and n > cap:  # MI355TTS_ERR_TOO_SMALL: frames_out holds the real counts
+                cap = n
+                continue
+            ffi.check(self.lib, rc)
+            return frames, (f32[:, :n] if f32 is not None else None), i16[:, :n]
+        raise AssertionError("unreachable")
+
+    def reserve(self, workers: int, glow: int = 0, vocoder: int = 0, max_batch: int = 1, max_ids: int = 256,
+                max_frames: int = 2048, denoiser: bool = False, max_pad_samples: int = 0):
+        """Pre-create per-call workers and size every workspace (`mi355tts_reserve`)."""
+        ffi.check(self.lib, self.lib.mi355tts_reserve(self._ctx, int(workers), int(glow), int(vocoder), int(max_batch), int(max_ids),
+                                                     int(max_frames), 1 if denoiser else 0, int(max_pad_samples)))
 
     def mel_from_numpy(self, mel: np.ndarray, frames=None, audio_settings=None) -> MelBatch:
         mel = np.ascontiguousarray(mel, np.float32)
@@ -230,15 +298,17 @@ class Engine:
         return self._hops[vocoder]
 
     def hifigan_infer(self, vocoder: int, mel: MelBatch, want_float: bool = True, want_int16: bool = True,
-                      denoiser_strength: float = 0.0):
-        """Returns (wav_f32 [B, N] or None, wav_i16 [B, N] or None), N = max_frames*hop;
-        row b holds frames[b]*hop samples followed by zeros."""
-        n = mel.max_frames * self.hop(vocoder)
+                      denoiser_strength: float = 0.0, pad_before: int = 0, pad_after: int = 0):
+        """Returns (wav_f32 [B, N] or None, wav_i16 [B, N] or None), N = pad_before + max_frames*hop + pad_after;
+        row b holds pad_before zeros, frames[b]*hop samples, then zeros (the SSML pauses of
+        `larynx/__init__.py:277-283`, written by the int16 kernel instead of np.pad)."""
+        n = mel.max_frames * self.hop(vocoder) + int(pad_before) + int(pad_after)
         f32 = np.empty((mel.batch, n), np.float32) if want_float else None
         i16 = np.empty((mel.batch, n), np.int16) if want_int16 else None
         ffi.check(
             self.lib,
-            self.lib.mi355tts_hifigan_infer(self._ctx, vocoder, mel.handle, float(denoiser_strength), ffi.ptr(f32), ffi.ptr(i16), n, 0),
+            self.lib.mi355tts_hifigan_infer_padded(self._ctx, vocoder, mel.handle, float(denoiser_strength), ffi.ptr(f32),
+                                                   ffi.ptr(i16), n, 0, int(pad_before), int(pad_after)),
         )
         return f32, i16
 
@@ -259,6 +329,13 @@ class Engine:
             ),
         )
         return y
+
+    def gauss_noise(self, seed: int, B: int, channels: int, T: int) -> np.ndarray:
+        """[B, channels, T] draws of the device noise generator (what `glow_infer` adds when no
+        explicit noise tensor is given)."""
+        out = np.empty((B, channels, T), np.float32)
+        ffi.check(self.lib, self.lib.mi355tts_op_gauss_noise(self._ctx, int(seed) & (2 ** 64 - 1), B, channels, T, out.ctypes.data))
+        return out
 
     def denoise(self, wav: np.ndarray, bias_spec: np.ndarray, strength: float) -> np.ndarray:
         wav = np.ascontiguousarray(wav, np.float32)

@@ -3,7 +3,9 @@
 from __future__ import annotations
 
 import copy
+import itertools
 import logging
+import os
 import typing
 
 import numpy as np
@@ -31,7 +33,8 @@ class HipGlowTextToSpeech(TextToSpeechModel):
       `audio_settings` attribute this object exposes to `_sentence_task` has those
       three switches off (the real ones are kept for the kernel);
     * extra settings `noise` (explicit N(0,1) tensor `[80, >=F]`, the parity mode)
-      and `seed` (device RNG) — the reference's noise is not reproducible from the
+      and `seed` (device RNG; default: a fresh seed per call, as the reference draws
+      fresh noise per call) — the reference's noise is not reproducible from the
       host (`torch.randn_like`, `glow_tts/models.py:348`).
     """
 
@@ -57,6 +60,10 @@ class HipGlowTextToSpeech(TextToSpeechModel):
             known = {k: v for k, v in cfg["audio"].items() if k in AudioSettings.__dataclass_fields__}
             self._audio_settings = AudioSettings(**known)
         self.phoneme_to_id: typing.Optional[typing.Dict[str, int]] = None
+        # The reference draws fresh noise on every call (`torch.randn_like`, glow_tts/models.py:348):
+        # without an explicit `seed` setting each call takes the next value of a per-model
+        # counter that starts at a random 63-bit number (thread-safe: itertools.count is atomic).
+        self._seeds = itertools.count(int.from_bytes(os.urandom(8), "little") >> 1)
 
     # -- `get_tts_model` does setattr(model, "audio_settings", ...) and `text_to_speech`
     #    reads it back with getattr (larynx/__init__.py:117-120, 362-363)
@@ -80,17 +87,18 @@ class HipGlowTextToSpeech(TextToSpeechModel):
 
     def phonemes_to_mels(self, phoneme_ids: np.ndarray, settings: typing.Optional[SettingsType] = None) -> ARRAY_OR_TENSOR:
         noise_scale, length_scale = self.noise_scale, self.length_scale
-        noise, seed = None, 0
+        noise, seed = None, None
         if settings:
             noise_scale = float(settings.get("noise_scale", noise_scale))
             length_scale = float(settings.get("length_scale", length_scale))
             if settings.get("speaker_id") is not None:
                 raise ValueError("multi-speaker voices are not supported by the HIP backend")
             noise = settings.get("noise")
-            seed = int(settings.get("seed", 0))
+            seed = settings.get("seed")
         ids = np.asarray(phoneme_ids, dtype=np.int64).reshape(-1)
         if ids.size == 0:
             raise ValueError("empty phoneme id sequence")
+        seed = next(self._seeds) if seed is None else int(seed)
         return self.engine.glow_infer(
             self.model_id, ids, noise_scale, length_scale, noise=noise, seed=seed, audio_settings=self._audio_settings
         )

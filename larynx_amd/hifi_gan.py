@@ -47,13 +47,20 @@ class HipHiFiGanVocoder(VocoderModel):
         self.denoiser_strength = float(config.denoiser_strength)
 
     def mels_to_audio(self, mels: ARRAY_OR_TENSOR, settings: typing.Optional[SettingsType] = None) -> np.ndarray:
+        return self.mels_to_audio_padded(mels, settings, 0, 0)
+
+    def mels_to_audio_padded(self, mels: ARRAY_OR_TENSOR, settings: typing.Optional[SettingsType] = None,
+                             pad_before: int = 0, pad_after: int = 0) -> np.ndarray:
+        """`mels_to_audio` with the SSML pauses of `_sentence_task` (`larynx/__init__.py:277-283`,
+        `np.pad` on the host there) written by the device's int16 kernel: `pad_before` zero
+        samples, the audio, `pad_after` zero samples."""
         strength = self.denoiser_strength
         if settings:
             strength = float(settings.get("denoiser_strength", strength))
         batch = mels if isinstance(mels, MelBatch) else self.engine.mel_from_numpy(np.asarray(mels, np.float32))
         _, i16 = self.engine.hifigan_infer(self.model_id, batch, want_float=False, want_int16=True,
-                                           denoiser_strength=max(strength, 0.0))
-        n = int(batch.frames[0]) * self.engine.hop(self.model_id)
+                                           denoiser_strength=max(strength, 0.0), pad_before=pad_before, pad_after=pad_after)
+        n = int(batch.frames[0]) * self.engine.hop(self.model_id) + int(pad_before) + int(pad_after)
         return i16[0, :n] if batch.batch == 1 else i16
 
     def mels_to_float(self, mels: ARRAY_OR_TENSOR, denoiser_strength: float = 0.0) -> np.ndarray:

@@ -81,8 +81,11 @@ def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[n
                      noise_scale: float = 0.667, length_scale: float = 1.0, seed: int = 0, audio_settings=None,
                      batch: int = 1) -> typing.Dict[int, np.ndarray]:
     """This rank's share of the work list -> {utterance index: int16 audio}.
-    `batch` > 1 runs length-bucketed micro-batches through one pair of calls each
-    (every row still equals its own batch-1 result: the kernels mask by row length)."""
+    `batch` > 1 runs length-bucketed micro-batches through one pair of calls each.  The
+    kernels mask by row length, so with `noise_scale == 0` (or explicit noise) every row equals
+    its own batch-1 result; the device RNG is keyed by (call seed, row, channel, frame), so with
+    `noise_scale != 0` a row of a micro-batch draws a different — equally distributed — noise
+    field than the same utterance would in a call of its own."""
     lengths = [len(r) for r in id_rows]
     mine = lpt_assign(lengths, world)[rank]
     out: typing.Dict[int, np.ndarray] = {}

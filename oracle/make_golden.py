@@ -185,9 +185,24 @@ def main():
         ("thorsten_medium_veg", HP.THORSTEN, HP.HIFIGAN_MEDIUM, fx["thorsten:haben_sie_ein_vegetarisches"], 0.667, 1.0),
         ("ljspeech_high_short5", HP.LJSPEECH, HP.HIFIGAN_HIGH, [3, 8, 4, 14, 2], 0.0, 1.0),
         ("ljspeech_high_long", HP.LJSPEECH, HP.HIFIGAN_HIGH, fx["ljspeech:it_took_me_quite_a_long_time_to_develop_a_voice"], 0.667, 1.0),
+        # BASELINE config 2 at S: the very utterance bench.py times first (P = 120 synthetic ids, length_scale 0.65
+        # -> ~620 frames), with recorded noise instead of the device RNG
+        ("ljspeech_high_S120", HP.LJSPEECH, HP.HIFIGAN_HIGH,
+         synthetic.synthetic_phoneme_ids(np.random.default_rng(1234), 120, HP.LJSPEECH.num_symbols), 0.667, 0.65),
     ]
+    # BASELINE config 4: thorsten + 'medium', B = 8 variable length: the five thorsten fixture
+    # sentences (19, 26, 31, 33, 64 ids) + synthetic rows of 47, 90, 120 ids.  The reference never batches
+    # (SURVEY F7), so every row goes through it at B = 1; the HIP path must reproduce each row inside ONE padded batch.
+    rng4 = np.random.default_rng(11)
+    rows4 = [fx["thorsten:ich_bin_allergisch"], fx["thorsten:mir_geht_es_gut"], fx["thorsten:konnen_sie_bitte"],
+             fx["thorsten:haben_sie_ein_vegetarisches"], fx["thorsten:fischers_fritze_fischt"]]
+    rows4 += [list(synthetic.synthetic_phoneme_ids(rng4, n, HP.THORSTEN.num_symbols)) for n in (47, 90, 120)]
+    assert [len(r) for r in rows4] == [19, 26, 31, 33, 64, 47, 90, 120]
+    for b, r in enumerate(rows4):
+        cases.append((f"batch8/thorsten_medium_row{b}", HP.THORSTEN, HP.HIFIGAN_MEDIUM, r, 0.667, 0.5))
     models = {}
     report = {}
+    batch_rows = []
     for name, ghp, vhp, ids, ns, ls in cases:
         gkey, vkey = ("g", ghp), ("v", vhp)
         if gkey not in models:
@@ -199,7 +214,11 @@ def main():
         gsd, gmodel = models[gkey]
         vsd, vmodel = models[vkey]
         ids = np.asarray(ids, np.int64)
-        noise = np.random.default_rng(1234).standard_normal((ghp.mel_channels, 16 * len(ids) + 64)).astype(np.float32)
+        # batch rows draw their noise from one [8, M, 2200] tensor (row b of the batch the HIP path will run)
+        if name.startswith("batch8/"):
+            noise = np.random.default_rng(4).standard_normal((8, ghp.mel_channels, 2200)).astype(np.float32)[int(name[-1])]
+        else:
+            noise = np.random.default_rng(1234).standard_normal((ghp.mel_channels, 16 * len(ids) + 64)).astype(np.float32)
         mel, mel_voc, wav, wav_i16, logw = ref_sentence(gmodel, vmodel, ra, ids, noise, ns, ls, audio_cfg)
         F = mel.shape[1]
         # --- oracle must reproduce the reference ---
@@ -245,8 +264,11 @@ def main():
             assert np.sqrt(np.mean((o_den - den[0]) ** 2)) < 2e-5
             report[name]["denoise_rms"] = float(np.sqrt(np.mean((o_den - den[0]) ** 2)))
             extra = dict(denoiser_strength=np.float32(strength), bias_spec=bias_spec[0, :, 0].astype(np.float32),
-                         wav_denoised=den[0][::3].astype(np.float32), wav_denoised_i16=den_i16[::3], wav_denoised_stride=np.int32(3))
-        keep_wav = wav if len(wav) <= 80000 else None
+                         wav_denoised=den[0].astype(np.float32), wav_denoised_i16=den_i16, wav_denoised_stride=np.int32(1))
+        if name.startswith("batch8/"):
+            batch_rows.append(dict(ids=ids, mel=mel.astype(np.float32), wav=wav.astype(np.float32), wav_i16=wav_i16))
+            continue
+        keep_wav = wav  # full waveforms (round 1 stored 1 sample in 7 of the long ones)
         np.savez_compressed(
             GOLDEN / f"{name}.npz",
             ids=ids,
@@ -262,6 +284,13 @@ def main():
             vocoder=json.dumps(vhp.to_config()),
             **extra,
         )
+    (GOLDEN / "batch8").mkdir(exist_ok=True)
+    np.savez_compressed(
+        GOLDEN / "batch8" / "thorsten_medium_batch8.npz",
+        noise_seed=np.int32(4), noise_scale=np.float32(0.667), length_scale=np.float32(0.5),
+        glow=json.dumps(HP.THORSTEN.to_config()), vocoder=json.dumps(HP.HIFIGAN_MEDIUM.to_config()),
+        **{f"{k}{b}": r[k] for b, r in enumerate(batch_rows) for k in ("ids", "mel", "wav")},  # int16 = audio_float_to_int16(wav)
+    )
     (GOLDEN / "oracle_vs_reference.json").write_text(json.dumps(report, indent=1, sort_keys=True))
 
 

@@ -16,3 +16,20 @@ def load_case(name):
     d["voc_hp"] = HP.HifiGanHParams.from_config(json.loads(str(d["vocoder"])))
     d["noise"] = np.random.default_rng(1234).standard_normal((d["glow_hp"].mel_channels, 16 * len(d["ids"]) + 64)).astype(np.float32)
     return d
+
+
+def load_batch8():
+    """BASELINE config 4: rows of the thorsten + 'medium' B = 8 batch, each produced by the
+    reference at B = 1 (oracle/make_golden.py)."""
+    z = np.load(GOLDEN / "batch8" / "thorsten_medium_batch8.npz")
+    ghp = HP.GlowHParams.from_config(json.loads(str(z["glow"])))
+    return dict(
+        glow_hp=ghp,
+        voc_hp=HP.HifiGanHParams.from_config(json.loads(str(z["vocoder"]))),
+        noise_scale=float(z["noise_scale"]),
+        length_scale=float(z["length_scale"]),
+        noise=np.random.default_rng(int(z["noise_seed"])).standard_normal((8, ghp.mel_channels, 2200)).astype(np.float32),
+        ids=[z[f"ids{b}"] for b in range(8)],
+        mel=[z[f"mel{b}"] for b in range(8)],
+        wav=[z[f"wav{b}"] for b in range(8)],
+    )

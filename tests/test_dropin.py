@@ -1,6 +1,7 @@
 """The reference-shaped host interface (`larynx_amd.load_tts_model`,
 `load_vocoder_model`, `sentence_task`, `phonemes_to_speech`) over a voice
-directory on disk, on the emulator build."""
+directory on disk — every test runs twice: on the emulator build (CPU CI) and,
+under `-m gpu`, on the real `libmi355tts.so`."""
 import json
 
 import numpy as np
@@ -12,6 +13,15 @@ from larynx_amd import synthetic
 from larynx_amd.audio import ljspeech_audio_settings
 from larynx_amd.constants import InferenceBackend, TextToSpeechType, VocoderType
 from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+
+@pytest.fixture(scope="module", params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def emu_library(request):
+    """Library path handed to the host classes: the emulator build, or None = the hipcc-built
+    in-tree library (the name is kept so the tests read the same for both)."""
+    if request.param == "emu":
+        return request.getfixturevalue("emu_library_path")
+    return None
 
 
 @pytest.fixture(scope="module")

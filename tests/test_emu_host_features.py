@@ -1,0 +1,183 @@
+"""Host-runtime features of the C ABI on the CPU emulator build: the fused
+`mi355tts_synthesize` call, device-side pause padding, `mi355tts_reserve`, the
+load-adaptive vocoder schedule, unusual-but-legal vocoder configurations and
+hyper-parameter validation (round-1 advisor findings)."""
+import threading
+
+import numpy as np
+import pytest
+
+from larynx_amd import ffi
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+
+@pytest.fixture(scope="module")
+def tiny(emu_engine):
+    gsd = synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7)
+    vsd = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7)
+    return dict(gsd=gsd, vsd=vsd, g=emu_engine.load_glow(HP.TINY_GLOW, gsd), v=emu_engine.load_hifigan(HP.TINY_HIFIGAN, vsd))
+
+
+def check_synthesize_equals_two_calls(eng, g, v, num_symbols, hop, lens=(13, 7, 21)):
+    rng = np.random.default_rng(41)
+    s = ljspeech_audio_settings()
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, num_symbols) for n in lens]
+    for ids in (rows[0], rows):
+        mel = eng.glow_infer(g, ids, 0.667, 1.0, seed=99, audio_settings=s)
+        f2, i2 = eng.hifigan_infer(v, mel, pad_before=5, pad_after=9)
+        frames, f1, i1 = eng.synthesize(g, v, ids, 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9, want_float=True)
+        assert np.array_equal(frames, mel.frames)
+        assert np.array_equal(i1, i2) and np.array_equal(f1, f2)
+        for b in range(len(frames)):
+            n = int(frames[b]) * hop
+            assert np.all(i1[b, :5] == 0) and np.all(i1[b, 5 + n :] == 0) and np.all(f1[b, :5] == 0) and np.all(f1[b, 5 + n :] == 0)
+        # the padded row is the un-padded audio shifted by pad_before
+        _, i0 = eng.hifigan_infer(v, mel)
+        for b in range(len(frames)):
+            n = int(frames[b]) * hop
+            assert np.array_equal(i1[b, 5 : 5 + n], i0[b, :n])
+    # a guess that is too small is retried with a bigger buffer
+    frames, _, i3 = eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9, frames_per_id_guess=0.2)
+    assert np.array_equal(i3, eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9)[2])
+
+
+def test_synthesize_equals_two_calls(emu_engine, tiny):
+    check_synthesize_equals_two_calls(emu_engine, tiny["g"], tiny["v"], HP.TINY_GLOW.num_symbols, HP.TINY_HIFIGAN.hop)
+
+
+def test_synthesize_matches_oracle_with_denoiser_free_path(emu_engine, tiny):
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(5), 15, HP.TINY_GLOW.num_symbols)
+    s = ljspeech_audio_settings()
+    frames, f32, i16 = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0, audio_settings=s, want_float=True)
+    ref_mel = glow_tts_np.glow_tts_infer(tiny["gsd"], HP.TINY_GLOW, ids, None, 0.0, 1.0)
+    ref = hifi_gan_np.hifigan_infer(tiny["vsd"], HP.TINY_HIFIGAN, audio_np.mel_to_vocoder_input(ref_mel, s))
+    assert int(frames[0]) == ref_mel.shape[1]
+    assert np.sqrt(np.mean((f32[0] - ref) ** 2)) < 1e-4
+    assert np.abs(i16[0].astype(np.int32) - audio_np.audio_float_to_int16(ref).astype(np.int32)).max() <= 1
+
+
+def test_reserve_then_calls_do_not_grow(emu_engine, tiny):
+    emu_engine.reserve(3, tiny["g"], tiny["v"], max_batch=2, max_ids=40, max_frames=400, denoiser=False, max_pad_samples=64)
+    with pytest.raises(ffi.Mi355ttsError):
+        emu_engine.reserve(0, tiny["g"], tiny["v"])
+    with pytest.raises(ffi.Mi355ttsError):
+        emu_engine.reserve(1, 12345, tiny["v"])
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(2), 30, HP.TINY_GLOW.num_symbols)
+    a = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0)[2]
+    b = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0)[2]
+    assert np.array_equal(a, b)
+
+
+def check_schedule_invariance(eng, v, num_mels, frames=33, threads=4):
+    """The vocoder forks its MRF chains onto side streams only while it has the GPU to
+    itself (`adaptive_schedule`); results must not depend on which form ran, nor on how many
+    calls are in flight."""
+    rng = np.random.default_rng(17)
+    melin = (rng.standard_normal((1, num_mels, frames)) * 2).astype(np.float32)
+    outs = {}
+    for adaptive in (0, 1):
+        eng.set_option("adaptive_schedule", adaptive)
+        outs[adaptive] = eng.hifigan_infer(v, eng.mel_from_numpy(melin))[0]
+    eng.set_option("adaptive_schedule", 1)
+    assert np.array_equal(outs[0], outs[1])
+    got = [None] * threads
+    gate = threading.Barrier(threads)
+
+    def work(i):
+        gate.wait()
+        for _ in range(3):
+            got[i] = eng.hifigan_infer(v, eng.mel_from_numpy(melin))[0]
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for g in got:
+        assert np.array_equal(g, outs[0])
+
+
+def test_adaptive_schedule_results_do_not_depend_on_load(emu_engine, tiny):
+    check_schedule_invariance(emu_engine, tiny["v"], HP.TINY_HIFIGAN.num_mels)
+
+
+def test_vocoder_with_four_resblock_kernels_and_odd_strides(emu_engine):
+    """num_kernels = 4 (> the 3 side-stream chains: runs the serial MRF form; round-1 advisor:
+    `outs[3]` overflow) and upsample rates (2, 2) with an odd frame count (stage lengths that
+    are not multiples of 4: row strides are padded, round-1 advisor)."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=32,
+                           resblock_kernel_sizes=(3, 5, 7, 3), resblock_dilation_sizes=((1, 2), (1, 3), (1, 1), (2, 1)), num_mels=16)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=51)
+    v = emu_engine.load_hifigan(hp, sd)
+    rng = np.random.default_rng(52)
+    for F in (7, 13):
+        melin = (rng.standard_normal((2, hp.num_mels, F)) * 2).astype(np.float32)
+        frames = np.array([F, F - 2], np.int32)
+        f32, _ = emu_engine.hifigan_infer(v, emu_engine.mel_from_numpy(melin, frames))
+        for b in range(2):
+            ref = hifi_gan_np.hifigan_infer(sd, hp, melin[b, :, : frames[b]])
+            n = frames[b] * hp.hop
+            assert np.sqrt(np.mean((f32[b, :n] - ref) ** 2)) < 1e-5
+            assert np.all(f32[b, n:] == 0)
+    emu_engine.unload(v)
+    hp3 = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=32,
+                            resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (1, 3), (1, 1)), num_mels=16)
+    sd3 = synthetic.make_hifigan_state_dict(hp3, seed=53)
+    v3 = emu_engine.load_hifigan(hp3, sd3)
+    melin = (rng.standard_normal((1, 16, 9)) * 2).astype(np.float32)
+    f32, _ = emu_engine.hifigan_infer(v3, emu_engine.mel_from_numpy(melin))
+    assert np.sqrt(np.mean((f32[0] - hifi_gan_np.hifigan_infer(sd3, hp3, melin[0])) ** 2)) < 1e-5
+    emu_engine.unload(v3)
+
+
+def test_bad_hparams_return_errors(emu_engine):
+    """`n_split = 0` used to divide by zero inside the validator (round-1 advisor)."""
+    import dataclasses
+
+    for bad in (dict(n_split=0), dict(n_sqz=0), dict(n_split=3), dict(n_block_layers=0)):
+        hp = dataclasses.replace(HP.TINY_GLOW, **bad)
+        with pytest.raises(ffi.Mi355ttsError):
+            ffi.manifest(emu_engine.lib, ffi.glow_hparams_c(hp))
+
+
+def test_long_input_durations_scan(emu_engine):
+    """More ids than the 64 lanes of the duration kernel's scan, ragged batch."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=32, filter_channels=32, filter_channels_dp=32, n_blocks_dec=1,
+                        n_layers_enc=1, n_block_layers=1, mel_channels=8)
+    sd = synthetic.make_glow_state_dict(hp, seed=61)
+    g = emu_engine.load_glow(hp, sd)
+    rng = np.random.default_rng(62)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, hp.num_symbols) for n in (131, 64, 65, 1)]
+    mel = emu_engine.glow_infer(g, rows, 0.0, 0.7)
+    for b, ids in enumerate(rows):
+        ref = glow_tts_np.glow_tts_infer(sd, hp, ids, None, 0.0, 0.7)
+        assert int(mel.frames[b]) == ref.shape[1]
+        np.testing.assert_allclose(mel.numpy("raw")[b, :, : ref.shape[1]], ref, atol=3e-5, rtol=1e-4)
+    emu_engine.unload(g)
+
+
+def test_fresh_seed_per_call_by_default(emu_library, tmp_path):
+    """Without an explicit `seed` every `phonemes_to_mels` call draws new noise, as the
+    reference's `torch.randn_like` does (round-1 advisor); an explicit seed repeats."""
+    import json
+
+    import larynx_amd
+    from larynx_amd.constants import TextToSpeechType
+
+    gdir = tmp_path / "tiny-glow_tts"
+    gdir.mkdir()
+    (gdir / "config.json").write_text(json.dumps(HP.TINY_GLOW.to_config()))
+    np.savez(gdir / "generator.npz", **synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=3))
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, library_path=emu_library)
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(2), 10, HP.TINY_GLOW.num_symbols)
+    a, b = np.asarray(tts.phonemes_to_mels(ids)), np.asarray(tts.phonemes_to_mels(ids))
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    c, d = np.asarray(tts.phonemes_to_mels(ids, {"seed": 5})), np.asarray(tts.phonemes_to_mels(ids, {"seed": 5}))
+    assert np.array_equal(c, d)
+
+
+def test_device_noise_is_standard_normal(emu_engine):
+    from tests.noise_check import check_gauss_noise
+
+    check_gauss_noise(emu_engine, 2, 16, 4000, ks_bound=1.95 / np.sqrt(2 * 16 * 4000))

@@ -105,10 +105,14 @@ def test_golden_reference_parity(gpu_engine, name):
     assert np.abs(raw - c["mel"]).max() <= 5e-5
     np.testing.assert_allclose(mel.numpy("vocoder")[0], c["mel_voc"], atol=5e-3, rtol=1e-3)
     wav, i16 = gpu_engine.hifigan_infer(v, mel)
-    st = int(c["wav_stride"])
-    rms = np.sqrt(np.mean((wav[0][::st] - c["wav"]) ** 2))
+    assert int(c["wav_stride"]) == 1 and wav.shape[1] == c["wav"].shape[0]  # every sample is compared
+    rms = np.sqrt(np.mean((wav[0] - c["wav"]) ** 2))
     assert rms <= WAV_RMS_TOL, rms
-    assert np.abs(i16[0][::st].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 2  # 1 LSB + peak round-off
+    assert np.abs(i16[0].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 1  # +-1 LSB
+    # the fused one-call entry point gives the same bits as the two calls
+    frames, f1, i1 = gpu_engine.synthesize(g, v, c["ids"], float(c["noise_scale"]), float(c["length_scale"]), noise=c["noise"],
+                                           audio_settings=s, want_float=True)
+    assert int(frames[0]) == c["mel"].shape[1] and np.array_equal(f1, wav) and np.array_equal(i1, i16)
 
 
 def test_serial_branch_schedule_matches_reference(gpu_engine):
@@ -130,10 +134,10 @@ def test_denoiser_matches_reference(gpu_engine):
     _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
     mb = gpu_engine.mel_from_numpy(c["mel_voc"])
     wav, i16 = gpu_engine.hifigan_infer(v, mb, denoiser_strength=float(c["denoiser_strength"]))
-    st = int(c["wav_denoised_stride"])
-    assert wav.shape[1] == c["mel_voc"].shape[1] * 256
-    assert np.sqrt(np.mean((wav[0][::st] - c["wav_denoised"]) ** 2)) <= 1e-4
-    assert np.abs(i16[0][::st].astype(np.int32) - c["wav_denoised_i16"].astype(np.int32)).max() <= 2
+    assert int(c["wav_denoised_stride"]) == 1
+    assert wav.shape[1] == c["mel_voc"].shape[1] * 256 == c["wav_denoised"].shape[0]
+    assert np.sqrt(np.mean((wav[0] - c["wav_denoised"]) ** 2)) <= 1e-4
+    assert np.abs(i16[0].astype(np.int32) - c["wav_denoised_i16"].astype(np.int32)).max() <= 1
     plain, _ = gpu_engine.hifigan_infer(v, mb)
     assert np.sqrt(np.mean((plain[0] - wav[0]) ** 2)) > 1e-3  # the denoiser did something
 
@@ -159,32 +163,60 @@ def test_vocoder_alone_on_reference_mel(gpu_engine):
     assert np.abs(i16[0].astype(np.int32) - c["wav_i16"].astype(np.int32)).max() <= 1
 
 
-def test_batch_rows_equal_single_rows(gpu_engine):
-    """BASELINE config 4 shape: thorsten + 'medium', B=8 variable length; every
-    row must equal its own B=1 result, padded tails exactly 0."""
-    ghp, vhp = HP.THORSTEN, HP.HIFIGAN_MEDIUM
+def test_config4_batch_rows_equal_the_reference(gpu_engine):
+    """BASELINE config 4: thorsten + 'medium', B = 8 variable length (P = 19 ... 120) in ONE
+    padded batch.  EVERY row's mel, float waveform and int16 against the golden row the
+    reference itself produced at B = 1 (the reference never batches; each row
+    must equal its own un-batched result), padded tails exactly 0."""
+    from tests.golden_util import load_batch8
+
+    c = load_batch8()
+    ghp, vhp = c["glow_hp"], c["voc_hp"]
     (gsd, g), (vsd, v) = models(gpu_engine, ghp, vhp)
-    rng = np.random.default_rng(11)
-    lens = [19, 26, 31, 33, 64, 47, 90, 120]
-    rows = [synthetic.synthetic_phoneme_ids(rng, n, ghp.num_symbols) for n in lens]
-    noise = rng.standard_normal((8, 80, 2200)).astype(np.float32)
     s = ljspeech_audio_settings()
-    mel = gpu_engine.glow_infer(g, rows, 0.667, 1.0, noise=noise, audio_settings=s)
+    mel = gpu_engine.glow_infer(g, c["ids"], c["noise_scale"], c["length_scale"], noise=c["noise"], audio_settings=s)
     wav, i16 = gpu_engine.hifigan_infer(v, mel)
     raw = mel.numpy("raw")
     hop = vhp.hop
-    for b in (0, 3, 7):
-        one = gpu_engine.glow_infer(g, rows[b], 0.667, 1.0, noise=noise[b], audio_settings=s)
-        F = int(one.frames[0])
+    for b in range(8):
+        F = c["mel"][b].shape[1]
         assert int(mel.frames[b]) == F
-        np.testing.assert_allclose(raw[b, :, :F], one.numpy("raw")[0], atol=1e-5)
+        assert np.abs(raw[b, :, :F] - c["mel"][b]).max() <= 5e-5
         assert np.all(raw[b, :, F:] == 0)
+        n = F * hop
+        assert n == c["wav"][b].shape[0]
+        rms = np.sqrt(np.mean((wav[b, :n] - c["wav"][b]) ** 2))
+        assert rms <= WAV_RMS_TOL, (b, rms)
+        ref16 = audio_np.audio_float_to_int16(c["wav"][b])  # larynx/audio.py:118-125 on the reference's float waveform
+        assert np.abs(i16[b, :n].astype(np.int32) - ref16.astype(np.int32)).max() <= 1
+        assert np.all(wav[b, n:] == 0) and np.all(i16[b, n:] == 0)
+    # and a row on its own gives the same bits as inside the batch
+    for b in (0, 5, 7):
+        one = gpu_engine.glow_infer(g, c["ids"][b], c["noise_scale"], c["length_scale"], noise=c["noise"][b], audio_settings=s)
+        F = int(one.frames[0])
+        np.testing.assert_allclose(raw[b, :, :F], one.numpy("raw")[0], atol=1e-5)
         w1, _ = gpu_engine.hifigan_infer(v, one)
         assert np.sqrt(np.mean((wav[b, : F * hop] - w1[0]) ** 2)) <= 1e-5
-        assert np.all(wav[b, F * hop :] == 0) and np.all(i16[b, F * hop :] == 0)
-    # and against the oracle for the shortest row
-    ref = glow_tts_np.glow_tts_infer(gsd, ghp, rows[0], noise[0], 0.667, 1.0)
-    assert np.abs(raw[0, :, : ref.shape[1]] - ref).max() <= 5e-5
+
+
+def test_device_noise_is_standard_normal(gpu_engine):
+    """The production noise mode (bench.py times it): 2 x 80 x 8192 = 1.3e6 draws."""
+    from tests.noise_check import check_gauss_noise
+
+    n = 2 * 80 * 8192
+    check_gauss_noise(gpu_engine, 2, 80, 8192, ks_bound=1.95 / np.sqrt(n))
+
+
+def test_host_feature_checks_on_the_device(gpu_engine):
+    """The emulator suite's host-runtime checks (fused call, pause padding, schedule
+    invariance under load) on the real build at full model sizes."""
+    from tests.test_emu_host_features import check_schedule_invariance, check_synthesize_equals_two_calls
+
+    (gsd, g), (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_MEDIUM)
+    check_synthesize_equals_two_calls(gpu_engine, g, v, HP.LJSPEECH.num_symbols, HP.HIFIGAN_MEDIUM.hop, lens=(40, 17, 63))
+    _, (_, vh) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    check_schedule_invariance(gpu_engine, vh, 80, frames=150, threads=6)
+    gpu_engine.reserve(4, g, vh, max_batch=1, max_ids=128, max_frames=1024, denoiser=True, max_pad_samples=22050)
 
 
 def test_standard_utterance_properties(gpu_engine):

@@ -22,7 +22,8 @@ def _glow_sd(hp):
 
 def test_golden_report_shows_oracle_pinned():
     rep = json.loads((GOLDEN / "oracle_vs_reference.json").read_text())
-    assert set(rep) == set(CASES)
+    assert {k for k in rep if "/" not in k} == set(CASES)
+    assert sum(k.startswith("batch8/") for k in rep) == 8
     for name, e in rep.items():
         assert e["mel"] < 2e-5 and e["wav_rms"] < 5e-6 and e["i16"] <= 1, (name, e)
 
@@ -72,3 +73,20 @@ def test_torch_operator_port_matches_numpy_oracle():
         a = hifi_gan_torch.hifigan_infer_torch(vsd, hp, mel)
         b = hifi_gan_np.hifigan_infer(vsd, hp, mel)
         assert np.sqrt(np.mean((a - b) ** 2)) < 2e-6
+
+
+def test_oracle_reproduces_config4_batch_rows():
+    """BASELINE config 4 golden (thorsten + 'medium', 8 rows, each through the reference at
+    B = 1): the oracle on the three shortest rows, GlowTTS and vocoder."""
+    from tests.golden_util import load_batch8
+
+    c = load_batch8()
+    gsd = synthetic.make_glow_state_dict(c["glow_hp"], seed=1234)
+    vsd = synthetic.make_hifigan_state_dict(c["voc_hp"], seed=1234)
+    s = ljspeech_audio_settings()
+    for b in (0, 1, 2):
+        mel = glow_tts_np.glow_tts_infer(gsd, c["glow_hp"], c["ids"][b], c["noise"][b], c["noise_scale"], c["length_scale"])
+        assert mel.shape == c["mel"][b].shape
+        np.testing.assert_allclose(mel, c["mel"][b], atol=2e-5)
+        wav = hifi_gan_np.hifigan_infer(vsd, c["voc_hp"], audio_np.mel_to_vocoder_input(c["mel"][b], s))
+        assert np.sqrt(np.mean((wav - c["wav"][b]) ** 2)) < 5e-6
