@@ -1,0 +1,270 @@
+"""The reference-side binding of INTEGRATION.md exercised against the REFERENCE'S OWN code.
+
+Runs only where `/root/reference` exists (the build container).  The reference package
+`larynx` is imported from there with stand-ins for the third-party modules this image lacks
+(`gruut`, `phonemes2ids`, `onnxruntime`, `dataclasses_json` — none of them on the hot path),
+INTEGRATION.md's edits are applied by monkey-patch (the `"hip"` backend value, the two
+`if backend == HIP` branches in `load_tts_model` / `load_vocoder_model`), and then the
+reference's real `text_to_speech` -> `get_tts_model` / `get_vocoder_model` -> `_sentence_task`
+(`larynx/__init__.py:47-190, 214-285, 293-376, 379-407, 415-508`) drives the HIP classes on
+the emulator build over a voice directory laid out as the reference expects.  The audio must
+equal (a) the oracle's int16 and (b) what the reference's own torch backend
+(`backend=InferenceBackend.PYTORCH`) produces through the very same entry point.
+"""
+import dataclasses
+import json
+import logging
+import os
+import sys
+import types
+import typing
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from larynx_amd.audio import ljspeech_audio_settings
+from oracle import audio_np, glow_tts_np, hifi_gan_np
+
+REF = Path(os.environ.get("LARYNX_REFERENCE", "/root/reference"))
+pytestmark = pytest.mark.skipif(not (REF / "larynx" / "__init__.py").is_file(), reason="needs the reference checkout")
+
+# shrunk hyper-parameters with the 80 mel channels the reference's Generator hard-codes (hifi_gan/models.py:153)
+GLOW = HP.GlowHParams(num_symbols=46, hidden_channels=32, filter_channels=64, filter_channels_dp=40, n_blocks_dec=2,
+                      n_layers_enc=2, n_block_layers=2, mel_channels=80)
+VOC = HP.HifiGanHParams(upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=32,
+                        resblock_kernel_sizes=(3, 5), resblock_dilation_sizes=((1, 3, 5), (1, 2, 3)), num_mels=80)  # ResBlock1 indexes dilation[0..2]
+
+
+# ------------------------------------------------------------------ stand-ins for absent third-party modules
+def _from_dict(cls, d):
+    hints = typing.get_type_hints(cls)
+    kw = {}
+    for f in dataclasses.fields(cls):
+        if f.name not in d:
+            continue
+        v, t = d[f.name], hints[f.name]
+        if dataclasses.is_dataclass(t) and isinstance(v, dict):
+            v = _from_dict(t, v)
+        elif isinstance(v, list):
+            v = _tuplify(v)
+        kw[f.name] = v
+    return cls(**kw)
+
+
+def _tuplify(v):
+    return tuple(_tuplify(x) for x in v) if isinstance(v, list) else v
+
+
+class _DataClassJsonMixin:
+    """Just enough of dataclasses_json for `TrainingConfig.load` (glow_tts/config.py:86-89)."""
+
+    @classmethod
+    def from_dict(cls, d):
+        return _from_dict(cls, d)
+
+    @classmethod
+    def from_json(cls, s):
+        return _from_dict(cls, json.loads(s))
+
+    def to_dict(self):
+        return dataclasses.asdict(self)
+
+
+class _Word:
+    def __init__(self, phonemes, pause_before_ms=0, pause_after_ms=0):
+        self.phonemes, self.pause_before_ms, self.pause_after_ms = phonemes, pause_before_ms, pause_after_ms
+        self.marks_before, self.marks_after = [], []
+
+
+class _Sentence:
+    """What `text_to_speech` reads off a gruut sentence (`larynx/__init__.py:72-175`)."""
+
+    def __init__(self, text, ids, pause_before_ms=0, pause_after_ms=0):
+        self.text = self.text_with_ws = text
+        self.voice = self.lang = None
+        self.words = [_Word(list(ids))]  # the stand-in "phonemes" of the one word ARE the fixture's ids
+        self.pause_before_ms, self.pause_after_ms = pause_before_ms, pause_after_ms
+        self.marks_before, self.marks_after = [], []
+
+    def __iter__(self):
+        return iter(self.words)
+
+
+SENTENCES: typing.List[_Sentence] = []
+
+
+@pytest.fixture(scope="module")
+def ref_larynx():
+    saved = {k: sys.modules.get(k) for k in ("gruut", "phonemes2ids", "onnxruntime", "dataclasses_json")}
+    gruut = types.ModuleType("gruut")
+    gruut.resolve_lang = lambda lang: lang
+    gruut.sentences = lambda text, lang=None, ssml=False, explicit_lang=False: iter(SENTENCES)
+    p2i = types.ModuleType("phonemes2ids")
+    p2i.load_phoneme_ids = lambda f: {line.split()[1]: int(line.split()[0]) for line in f if line.strip()}
+    p2i.phonemes2ids = lambda word_phonemes, phoneme_to_id, **kw: [i for w in word_phonemes for i in w]
+    ort = types.ModuleType("onnxruntime")
+    ort.SessionOptions = type("SessionOptions", (), {})
+    ort.GraphOptimizationLevel = types.SimpleNamespace(ORT_DISABLE_ALL=0)
+    ort.InferenceSession = type("InferenceSession", (), {})
+    dcj = types.ModuleType("dataclasses_json")
+    dcj.DataClassJsonMixin = _DataClassJsonMixin
+    sys.modules.update(gruut=gruut, phonemes2ids=p2i, onnxruntime=ort, dataclasses_json=dcj)
+    sys.path.insert(0, str(REF))
+    try:
+        import larynx  # the reference package, from /root/reference
+
+        assert Path(larynx.__file__).resolve().parent == (REF / "larynx").resolve()
+        yield larynx
+    finally:
+        sys.path.remove(str(REF))
+        for k in [m for m in sys.modules if m == "larynx" or m.startswith("larynx.") or m.split(".")[0] in ("glow_tts", "hifi_gan")]:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+@pytest.fixture(scope="module")
+def voices(tmp_path_factory):
+    """custom_voices_dir/en-us/ljspeech-glow_tts and custom_voices_dir/hifi_gan/universal_large, as
+    `get_tts_model` / `get_vocoder_model` look them up (`larynx/__init__.py:309-325, 437-446`), holding the
+    reference's own checkpoint format (`generator.pth`, glow_tts/checkpoint.py:41, hifi_gan/checkpoint.py:49)."""
+    import torch
+
+    root = tmp_path_factory.mktemp("voices")
+    gdir = root / "en-us" / "ljspeech-glow_tts"
+    vdir = root / "hifi_gan" / "universal_large"
+    gdir.mkdir(parents=True)
+    vdir.mkdir(parents=True)
+    gsd = synthetic.make_glow_state_dict(GLOW, seed=21)
+    vsd = synthetic.make_hifigan_state_dict(VOC, seed=22)
+    cfg = GLOW.to_config()
+    cfg["audio"].update({k: v for k, v in vars(ljspeech_audio_settings()).items() if k in (
+        "filter_length", "hop_length", "win_length", "sample_rate", "mel_fmin", "mel_fmax", "ref_level_db", "spec_gain",
+        "signal_norm", "min_level_db", "max_norm", "clip_norm", "symmetric_norm", "do_dynamic_range_compression",
+        "convert_db_to_amp")})
+    (gdir / "config.json").write_text(json.dumps(cfg))
+    (gdir / "phonemes.txt").write_text("".join(f"{i} p{i}\n" for i in range(GLOW.num_symbols)))
+    (vdir / "config.json").write_text(json.dumps(VOC.to_config()))
+    torch.save({"model": {k: torch.from_numpy(np.asarray(v)) for k, v in gsd.items()}, "global_step": 1}, gdir / "generator.pth")
+    torch.save({"generator": {k: torch.from_numpy(np.asarray(v)) for k, v in vsd.items()}}, vdir / "generator.pth")
+    return root, gsd, vsd
+
+
+def _apply_integration_edits(monkeypatch, larynx, library_path):
+    """INTEGRATION.md "The reference-side edits": `"hip"` as a backend value and the two
+    `if backend == InferenceBackend.HIP` branches, here as wrappers around the reference's
+    own `load_tts_model` / `load_vocoder_model` (same signatures, same config records)."""
+    from larynx.constants import TextToSpeechModelConfig, TextToSpeechType, VocoderModelConfig, VocoderType
+    from larynx_amd.glow_tts import HipGlowTextToSpeech
+    from larynx_amd.hifi_gan import HipHiFiGanVocoder
+
+    ref_load_tts, ref_load_voc = larynx.load_tts_model, larynx.load_vocoder_model
+
+    def load_tts_model(model_type, model_path, backend=None, no_optimizations=False, use_cuda=False, half=False):
+        if backend == "hip" and model_type == TextToSpeechType.GLOW_TTS:
+            config = TextToSpeechModelConfig(model_path=Path(model_path), session_options=None, use_cuda=use_cuda, half=half, backend=backend)
+            return HipGlowTextToSpeech(config, library_path=library_path)
+        return ref_load_tts(model_type, model_path, backend=backend, no_optimizations=no_optimizations, use_cuda=use_cuda, half=half)
+
+    def load_vocoder_model(model_type, model_path, backend=None, no_optimizations=False, use_cuda=False, half=False,
+                           denoiser_strength=0.0, executor=None):
+        if backend == "hip" and model_type == VocoderType.HIFI_GAN:
+            config = VocoderModelConfig(model_path=Path(model_path), session_options=None, use_cuda=use_cuda, half=half,
+                                        denoiser_strength=denoiser_strength, backend=backend)
+            return HipHiFiGanVocoder(config, executor=executor, library_path=library_path)
+        return ref_load_voc(model_type, model_path, backend=backend, no_optimizations=no_optimizations, use_cuda=use_cuda,
+                            half=half, denoiser_strength=denoiser_strength, executor=executor)
+
+    monkeypatch.setattr(larynx, "load_tts_model", load_tts_model)
+    monkeypatch.setattr(larynx, "load_vocoder_model", load_vocoder_model)
+    monkeypatch.setattr(larynx, "_TTS_MODEL_CACHE", {})
+    monkeypatch.setattr(larynx, "_VOCODER_MODEL_CACHE", {})
+
+
+def _fixture_sentences():
+    fx = json.loads((Path(__file__).parent / "golden" / "fixture_phoneme_ids.json").read_text())
+    return [
+        _Sentence("Be a voice, not an echo.", fx["ljspeech:be_a_voice_not_an_echo"], pause_before_ms=0, pause_after_ms=30),
+        _Sentence("I'm sorry Dave.", fx["ljspeech:im_sorry_dave"][:24], pause_before_ms=15, pause_after_ms=0),
+    ]
+
+
+def _oracle_audio(gsd, vsd, ids, before_ms, after_ms):
+    s = ljspeech_audio_settings()
+    mel = glow_tts_np.glow_tts_infer(gsd, GLOW, np.asarray(ids, np.int64), None, 0.0, 1.0)
+    i16 = audio_np.audio_float_to_int16(hifi_gan_np.hifigan_infer(vsd, VOC, audio_np.mel_to_vocoder_input(mel, s)))
+    return np.pad(i16, ((before_ms * 22050) // 1000, (after_ms * 22050) // 1000))
+
+
+def test_reference_text_to_speech_drives_the_hip_backend(ref_larynx, voices, emu_library_path, monkeypatch, caplog):
+    larynx = ref_larynx
+    root, gsd, vsd = voices
+    _apply_integration_edits(monkeypatch, larynx, emu_library_path)
+    SENTENCES[:] = _fixture_sentences()
+    with caplog.at_level(logging.DEBUG, logger="larynx"):
+        results = list(larynx.text_to_speech("ignored: the gruut stand-in yields the fixture sentences", voice_or_lang="ljspeech",
+                                             vocoder_or_quality="high", backend="hip", tts_settings={"noise_scale": 0.0},
+                                             custom_voices_dir=root))
+    assert [r.text for r in results] == [s.text for s in SENTENCES] and all(r.sample_rate == 22050 for r in results)
+    # the registry cached OUR classes and attached its attributes to them (larynx/__init__.py:362-370)
+    tts = larynx._TTS_MODEL_CACHE["en-us_ljspeech-glow_tts"]
+    assert type(tts).__name__ == "HipGlowTextToSpeech" and len(tts.phoneme_to_id) == GLOW.num_symbols
+    assert type(larynx._VOCODER_MODEL_CACHE["high"]).__name__ == "HipHiFiGanVocoder"
+    # the reference's _sentence_task logged its lines around our models, transforms skipped (fused in-kernel)
+    text = caplog.text
+    assert "Running text to speech model (HipGlowTextToSpeech)" in text and "Running vocoder model (HipHiFiGanVocoder)" in text
+    assert "Got mels in" in text and "Got audio in" in text and "Real-time factor" in text
+    for sent, r in zip(SENTENCES, results):
+        want = _oracle_audio(gsd, vsd, sent.words[0].phonemes, sent.pause_before_ms, sent.pause_after_ms)
+        assert r.audio.dtype == np.int16 and r.audio.shape == want.shape
+        assert np.abs(r.audio.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_hip_backend_equals_the_references_own_torch_backend(ref_larynx, voices, emu_library_path, monkeypatch):
+    """Same entry point, same voice directory, `backend="pytorch"` (the reference's in-tree torch
+    modules, larynx/glow_tts.py:66-95, larynx/hifi_gan.py:71-100) vs `backend="hip"`."""
+    larynx = ref_larynx
+    from larynx.constants import InferenceBackend
+
+    root, gsd, vsd = voices
+    SENTENCES[:] = _fixture_sentences()
+    _apply_integration_edits(monkeypatch, larynx, emu_library_path)
+    kw = dict(voice_or_lang="ljspeech", vocoder_or_quality="high", tts_settings={"noise_scale": 0.0}, custom_voices_dir=root)
+    ref = [r.audio for r in larynx.text_to_speech("x", backend=InferenceBackend.PYTORCH, **kw)]
+    assert type(larynx._TTS_MODEL_CACHE["en-us_ljspeech-glow_tts"]).__name__ == "GlowTextToSpeech"
+    monkeypatch.setattr(larynx, "_TTS_MODEL_CACHE", {})
+    monkeypatch.setattr(larynx, "_VOCODER_MODEL_CACHE", {})
+    hip = [r.audio for r in larynx.text_to_speech("x", backend="hip", **kw)]
+    assert len(ref) == len(hip) == 2
+    for a, b in zip(ref, hip):
+        assert a.shape == b.shape and a.dtype == b.dtype == np.int16
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+
+
+def test_reference_sentence_task_with_mixed_models(ref_larynx, voices, emu_library_path, monkeypatch):
+    """`_sentence_task` itself (larynx/__init__.py:214-285) with the reference's torch GlowTTS in front of
+    the HIP vocoder: the numpy mel transforms run on the host (un-fused settings), the vocoder takes the array."""
+    larynx = ref_larynx
+    from larynx.audio import AudioSettings
+    from larynx.constants import InferenceBackend
+
+    root, gsd, vsd = voices
+    _apply_integration_edits(monkeypatch, larynx, emu_library_path)
+    tts = larynx.load_tts_model("glow_tts", root / "en-us" / "ljspeech-glow_tts", backend=InferenceBackend.PYTORCH)
+    voc = larynx.load_vocoder_model("hifi_gan", root / "hifi_gan" / "universal_large", backend="hip")
+    ids = np.asarray(_fixture_sentences()[0].words[0].phonemes, np.int64)
+    settings = AudioSettings(**json.loads((root / "en-us" / "ljspeech-glow_tts" / "config.json").read_text())["audio"])
+
+    class AsArray:  # the torch backend returns a tensor; the HIP vocoder takes what the ONNX path returns: an ndarray
+        def phonemes_to_mels(self, phoneme_ids, settings=None):
+            return tts.phonemes_to_mels(phoneme_ids, settings=settings).numpy()
+
+    audio = larynx._sentence_task("t", ids, settings, AsArray(), {"noise_scale": 0.0}, voc, None, pause_before_ms=0, pause_after_ms=20)
+    want = _oracle_audio(gsd, vsd, ids, 0, 20)
+    assert audio.shape == want.shape and np.abs(audio.astype(np.int32) - want.astype(np.int32)).max() <= 1
