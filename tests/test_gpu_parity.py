@@ -309,12 +309,14 @@ def test_long_utterance_and_three_resident_voices(gpu_engine):
 
 
 def test_device_resident_mel_input(gpu_engine):
-    """`mi355tts_mel_from_buffer` with MI355TTS_IN_DEVICE: a mel produced elsewhere on the
-    GPU (here a raw hipMalloc buffer) goes to the vocoder without a host round trip and
-    gives the same waveform as the host-array path, including the fused mel transforms."""
-    import ctypes
+    """`mi355tts_mel_from_buffer` with MI355TTS_IN_DEVICE: a mel produced elsewhere on the GPU
+    (here a torch tensor — north_star: "PyTorch-ROCm tensors for I/O only") goes to the vocoder
+    without a host round trip and gives the same waveform as the host-array path, including the
+    fused mel transforms; and MI355TTS_OUT_DEVICE writes the waveform into a torch tensor."""
+    import torch
 
-    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
+    from larynx_amd import ffi
+
     _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_LOW)
     s = ljspeech_audio_settings()
     rng = np.random.default_rng(17)
@@ -322,16 +324,19 @@ def test_device_resident_mel_input(gpu_engine):
     frames = np.array([96, 70], np.int32)
     host = gpu_engine.mel_from_numpy(raw, frames=frames, audio_settings=s)
     w_host, i_host = gpu_engine.hifigan_infer(v, host)
-    dptr = ctypes.c_void_p()
-    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(raw.nbytes)) == 0
-    try:
-        assert hip.hipMemcpy(dptr, raw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(raw.nbytes), 1) == 0  # hipMemcpyHostToDevice
-        dev = gpu_engine.mel_from_device(dptr.value, frames, 80, 96, audio_settings=s)
-        w_dev, i_dev = gpu_engine.hifigan_infer(v, dev)
-        dev.free()
-    finally:
-        hip.hipFree(dptr)
+    t = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    dev = gpu_engine.mel_from_device(t.data_ptr(), frames, 80, 96, audio_settings=s)
+    w_dev, i_dev = gpu_engine.hifigan_infer(v, dev)
+    n = 96 * 256
+    out_f = torch.full((2, n + 8), 7.0, dtype=torch.float32, device="cuda")
+    out_i = torch.full((2, n + 8), 7, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    gpu_engine.hifigan_infer_raw(v, dev, out_f.data_ptr(), out_i.data_ptr(), n + 8, flags=ffi.OUT_DEVICE)
+    dev.free()
     assert np.array_equal(w_host, w_dev) and np.array_equal(i_host, i_dev)
+    assert np.array_equal(out_f.cpu().numpy()[:, :n], w_host) and np.array_equal(out_i.cpu().numpy()[:, :n], i_host)
+    assert np.all(out_f.cpu().numpy()[:, n:] == 0) and np.all(out_i.cpu().numpy()[:, n:] == 0)  # tail up to wav_ld zero-filled
     ref = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_LOW, audio_np.mel_to_vocoder_input(raw[1, :, :70], s))
     assert np.sqrt(np.mean((w_dev[1, : 70 * 256] - ref) ** 2)) <= 2e-5 and np.all(w_dev[1, 70 * 256 :] == 0)
 
