@@ -306,11 +306,13 @@ def main():
         step(0, 0, 0.005)
     barrier()
 
-    # ---- profiled pass: HIP events around every launch, MRF chains serialised on one
-    # stream so each kernel is timed alone (its duration is what the roofline uses)
+    # ---- profiled pass: HIP events around every launch.  The product schedule keeps a call on ONE
+    # stream (the three MRF chains' same-geometry convs go out as one grouped launch), so every
+    # launch is timed alone on the GPU and its duration is what the roofline uses.
+    # --serial-branches times the un-grouped, one-conv-per-launch form instead.
     eng.set_profiling(True)
-    eng.set_option("serial_branches", 1)
-    step(W)  # the serial schedule's workspace shape, outside the measured pass
+    eng.set_option("serial_branches", 1 if args.serial_branches else 0)
+    step(W)  # that schedule's workspace shape, outside the measured pass
     eng.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -468,7 +470,7 @@ def main():
             },
             "weight_broadcast_seconds": broadcast_s if world > 1 else None,
             "roofline": {
-                "kernel": "HiFi-GAN ResBlock launches: conv_mfma_kernel (wide stages) + resblock_pair_kernel (fused conv pairs)",
+                "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (fused conv pairs, 64/32-channel stages)",
                 "bound": "mfma",
                 "achieved": dom_tf,
                 "peak": FP32_PEAK_TFLOPS,
@@ -481,9 +483,10 @@ def main():
                 "avg_launch_us": 1e3 * dom["ms"] / max(1, dom["launches"]),
                 "share_of_step_time": dom["ms"] / (1e3 * dt_prof),
                 "all_conv_mfma_ms_per_step": all_conv_ms / K,
-                "schedule": "serial_branches=1: the three MRF chains of a stage run one after another on ONE stream so every "
-                            "kernel is timed alone; the product schedule (ms_per_step) forks them onto three streams when a "
-                            "call has the GPU to itself, so the class's wall time there is shorter than the sum of its launches",
+                "schedule": ("serial_branches=1: one conv (or fused conv pair) per launch, the three MRF chains one after another "
+                             "on one stream" if args.serial_branches else
+                             "product schedule: one stream per call; the same-geometry convs (or fused conv pairs) of the three MRF "
+                             "chains of a step are ONE grouped launch (conv_group_kernel / pair_group_kernel), each launch timed alone"),
                 "timing": "HIP events on the launch stream around every launch, profiled pass of the same K steps",
             },
             "profile_ms_per_step": {k_: v_["ms"] / K for k_, v_ in prof.items()},

@@ -108,19 +108,33 @@ struct ConvArgs {
 // neighbouring time tiles through the halo) should meet in ONE L2, so the linear id is
 // re-dealt: XCD x gets a contiguous run of tiles, m-tile fastest.  Bijective for any n
 // (MI355X_MICROARCH.md, T1); a wrong placement guess costs speed, never correctness.
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+__device__ __forceinline__ void xcd_tile_lin(int lin, int gx, int gy, int& tx, int& ty) {
   const int n = gx * gy;
-  const int lin = blockIdx.x + blockIdx.y * gx;
   const int xcd = lin & 7, slot = lin >> 3;
   const int q = n >> 3, r = n & 7;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   ty = id % gy;
   tx = id / gy;
 }
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+  xcd_tile_lin(blockIdx.x + blockIdx.y * gx, gx, gy, tx, ty);
+}
 
+// LDS floats one workgroup of a tile shape needs (staging double buffer, reused by the k-group reduction)
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
-// (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
-__global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
+constexpr int conv_lds_floats() {
+  constexpr bool SCATTER = (EPI == EPI_LINEAR || EPI == EPI_GATE);
+  constexpr int NBR = (SCATTER && NB > 2) ? 1 : NB;
+  constexpr int RED = (KS - 1) * WN * NBR * 16 * 64;
+  constexpr int XS = 2 * CI_C * (WN * NB * 32 + HALO);
+  return XS > RED ? XS : RED;
+}
+
+// One workgroup's tile of the implicit GEMM: rows [32*MB*tile_y, +32*MB) x columns [T_T*tile_x, +T_T) of
+// batch row b.  `xs` = conv_lds_floats<...>() floats of LDS.  Called by conv_mfma_kernel (one conv per
+// launch) and by conv_group_kernel (the same-shaped convs of the three MRF chains in ONE launch).
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
   // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
   // (NB blocks of 32 columns each); the KS k-groups split the staged input
   // channels between them (octet o goes to group o % KS) and are summed through
@@ -139,20 +153,14 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
   constexpr bool SCATTER = (EPI == EPI_LINEAR || EPI == EPI_GATE);
   constexpr int NBR = (SCATTER && NB > 2) ? 1 : NB;
   constexpr int RED = (KS - 1) * WN * NBR * 16 * 64;
-  constexpr int XS = 2 * CI_C * XW;
-  constexpr int LDSF = XS > RED ? XS : RED;
+  constexpr int LDSF = conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI>();
   static_assert(CI_C % 8 == 0 && CI_C % NWAVES == 0 && OCTS % KS == 0, "bad tile parameters");
-
-  __shared__ float xs[LDSF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wn = wave % WN;
   const int kg = wave / WN;
-  const int b = blockIdx.z;
-  int tile_x, tile_y;
-  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
   const int t0 = tile_x * T_T;
   const int mt0 = tile_y * MB;
 
@@ -713,6 +721,56 @@ __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB =
         }
       }
     }
+  }
+}
+
+
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+// (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
+__global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
+  __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI>()];
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI>(a, tile_x, tile_y, blockIdx.z, xs);
+}
+
+// The MRF chains of a HiFi-GAN stage (hifi_gan/models.py:191-197) run convs of the SAME geometry
+// (channels, length, tile shape) that differ only in tap count — K0 >= K1 >= K2 — dilation and
+// weights.  At batch 1 one such conv cannot fill the chip (a few hundred to ~1200 workgroups of
+// ~10 us: launch ramp, tail quantisation and every workgroup's prologue/epilogue are exposed), so
+// the three are issued as ONE launch: a 1-D grid whose first n0 workgroups are conv 0's tiles
+// (the longest-running ones first), the next n1 conv 1's, the rest conv 2's.  Each tile runs
+// exactly the code of conv_mfma_kernel, so results are bit-identical to three launches.
+// Group sizes are padded to multiples of 8 so a tile's XCD (workgroup id % 8) is the one
+// xcd_tile_lin assumes.
+struct ConvGroupArgs {
+  ConvArgs c[3];
+  int gx[3], gy[3];  // tile grid of each member (x = time tiles, y = row tiles)
+  int off[4];        // first workgroup of each member (multiples of 8), off[3] = grid size
+};
+template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2>
+__global__ __launch_bounds__(64 * WN * KS, (NB == 1 && MB == 2) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {
+  constexpr int L0 = conv_lds_floats<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR>();
+  constexpr int L1 = conv_lds_floats<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR>();
+  constexpr int L2 = conv_lds_floats<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR>();
+  __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
+  const int lin = blockIdx.x;
+  const int b = blockIdx.z;
+  int tx, ty;
+  if (lin < g.off[1]) {
+    if (lin >= g.gx[0] * g.gy[0]) return;
+    xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
+    conv_tile<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR>(g.c[0], tx, ty, b, xs);
+  } else if (lin < g.off[2]) {
+    const int l = lin - g.off[1];
+    if (l >= g.gx[1] * g.gy[1]) return;
+    xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
+    conv_tile<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR>(g.c[1], tx, ty, b, xs);
+  } else {
+    const int l = lin - g.off[2];
+    if (l >= g.gx[2] * g.gy[2]) return;
+    xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
+    conv_tile<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR>(g.c[2], tx, ty, b, xs);
   }
 }
 

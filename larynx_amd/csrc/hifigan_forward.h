@@ -173,7 +173,12 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   // `serial_branches` (profiling / tests) additionally folds the average into the chains'
   // last epilogues (in-place accumulation, one output buffer).
   const bool split_out = hifi_split_out(ctx, h);
-  const bool concurrent = split_out && !(ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1);
+  // grouped (default): the chains stay on ONE stream and the same-geometry launches of a step go out as
+  // one grouped launch (conv_group_kernel / pair_group_kernel) — the chip is filled from one launch, with
+  // no stream fork/join and independently of what else is in flight.  "mrf_group" = 0 restores the
+  // round-1 schedule (fork onto three streams while the call has the GPU to itself).
+  const bool grouped = split_out && nk == 3 && ctx->mrf_group;
+  const bool concurrent = split_out && !grouped && !(ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1);
   if (concurrent && !w->aux[0]) {
     for (int i = 0; i < 2; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&w->aux[i], hipStreamNonBlocking));
@@ -243,64 +248,127 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
       HIPCHECK(hipEventRecord(w->ev_fork, s));
       for (int j = 1; j < nk; ++j) HIPCHECK(hipStreamWaitEvent(w->aux[j - 1], w->ev_fork, 0));
     }
+    // per-chain buffers and running input (MRF: resblocks on the same input, models.py:191-197)
     float* outs[MI355TTS_MAX_STAGES] = {nullptr};
-    for (int j = 0; j < nk; ++j) {  // MRF: resblocks on the same input (models.py:191-197)
-      const int kk = h.resblock_kernel_sizes[j];
-      hipStream_t sj = (concurrent && j > 0) ? w->aux[j - 1] : s;
+    struct Chain {
       float *tb, *pa, *pb, *dst_last;
+      const float* rin;
+      hipStream_t st;
+    } chn[MI355TTS_MAX_STAGES];
+    for (int j = 0; j < nk; ++j) {
+      Chain& c = chn[j];
       if (split_out) {
         // per-chain scratch: buf[2 + 4j .. 2 + 4j + 3] = {t, ping, out(flip 0), out(flip 1)}
-        tb = buf[2 + 4 * j];
-        pa = buf[2 + 4 * j + 1];
-        pb = buf[2 + 4 * j + 2 + (flip ^ 1)];  // last stage's output: dead once the upsampler (before the fork) has read it
-        dst_last = buf[2 + 4 * j + 2 + flip];
+        c.tb = buf[2 + 4 * j];
+        c.pa = buf[2 + 4 * j + 1];
+        c.pb = buf[2 + 4 * j + 2 + (flip ^ 1)];  // last stage's output: dead once the upsampler (before the fork) has read it
+        c.dst_last = buf[2 + 4 * j + 2 + flip];
       } else {
-        tb = buf[2];
-        pa = buf[3];
-        pb = buf[4];
-        dst_last = buf[5];
+        c.tb = buf[2];
+        c.pa = buf[3];
+        c.pb = buf[4];
+        c.dst_last = buf[5];
       }
-      outs[j] = dst_last;
-      const float* rin = xu;
-      for (int d = 0; d < h.num_dilations; ++d) {
-        const HifiResConv& rc = hm->rb[i][j][d];
-        const bool last = d == h.num_dilations - 1;
-        float* dst = last ? dst_last : ((d & 1) ? pb : pa);
-        if (!dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
-        if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
-          {
-            const float pa_alpha = (last && !split_out) ? inv_nk : 1.0f;
-            const int pa_accum = (last && !split_out) ? (j > 0) : 0;
-            const int fr = launch_pair(ctx, w, rc.c1, rc.c2, rin, dst, bs, ldo, d_frames, mul, rc.dil, pa_alpha, pa_accum, B, Lout, sj, voc_host_len);
-            if (fr < 0) return fr;
-            if (fr == 0) {
-              rin = dst;
-              continue;
+      c.rin = xu;
+      c.st = (concurrent && j > 0) ? w->aux[j - 1] : s;
+      outs[j] = c.dst_last;
+    }
+    const int nd = h.num_dilations;
+    // One dilation step of chain j, planned: the fused pair if its geometry is covered, else conv1 (+ conv2)
+    struct Step {
+      PairPlan pair;
+      ConvPlan c1, c2;
+      float* dst;
+    };
+    auto plan_step = [&](int j, int d, Step& sp) -> int {
+      const HifiResConv& rc = hm->rb[i][j][d];
+      const int kk = h.resblock_kernel_sizes[j];
+      Chain& c = chn[j];
+      const bool last = d == nd - 1;
+      sp.dst = last ? c.dst_last : ((d & 1) ? c.pb : c.pa);
+      if (!sp.dst) return fail(MI355TTS_ERR_INVALID, "internal: resblock scratch aliasing");
+      const bool fold = last && !split_out;  // serial form: the MRF average is folded into the chains' last epilogues
+      sp.pair.ok = false;
+      if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
+        plan_pair(rc.c1, rc.c2, c.rin, sp.dst, bs, ldo, d_frames, mul, rc.dil, fold ? inv_nk : 1.0f, fold ? (j > 0) : 0, B, Lout,
+                  voc_host_len, &sp.pair);
+        if (sp.pair.ok) return 0;
+        ConvArgs a = base_args(c.rin, bs, ldo, d_frames, mul, c.tb, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+        a.in_slope = 0.1f;
+        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1));
+        ConvArgs c2 = base_args(c.tb, bs, ldo, d_frames, mul, sp.dst, bs, ldo, d_frames, mul, 1, (kk - 1) / 2);
+        c2.in_slope = 0.1f;
+        c2.res = c.rin;
+        if (fold) {
+          c2.alpha = inv_nk;
+          c2.accum = j > 0;
+        }
+        CHECK(plan_conv(rc.c2, c2, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c2));
+      } else {  // ResBlock2.forward, models.py:136-141
+        ConvArgs a = base_args(c.rin, bs, ldo, d_frames, mul, sp.dst, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
+        a.in_slope = 0.1f;
+        a.res = c.rin;
+        if (fold) {
+          a.alpha = inv_nk;
+          a.accum = j > 0;
+        }
+        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1));
+        sp.c2.empty = true;
+      }
+      return 0;
+    };
+    auto run_step_alone = [&](int j, const Step& sp) -> int {
+      if (sp.pair.ok) return run_pair(ctx, w, sp.pair, chn[j].st);
+      CHECK(run_plan(ctx, w, sp.c1, chn[j].st));
+      return run_plan(ctx, w, sp.c2, chn[j].st);
+    };
+    if (split_out) {
+      // dilation-major: step d of every chain before step d + 1 of any — the chains have their own
+      // buffers, and the same-geometry launches of a step can go out as ONE grouped launch
+      for (int d = 0; d < nd; ++d) {
+        Step sp[3];
+        for (int j = 0; j < nk; ++j) CHECK(plan_step(j, d, sp[j]));
+        bool done = false;
+        if (grouped) {
+          bool all_pair = true, none_pair = true;
+          for (int j = 0; j < nk; ++j) {
+            all_pair = all_pair && sp[j].pair.ok;
+            none_pair = none_pair && !sp[j].pair.ok;
+          }
+          if (all_pair) {
+            PairPlan pp[3] = {sp[0].pair, sp[1].pair, sp[2].pair};
+            const int rc = run_pair_group(ctx, w, pp, nk, s);
+            if (rc < 0) return rc;
+            done = rc == 0;
+          } else if (none_pair) {
+            ConvPlan a[3] = {sp[0].c1, sp[1].c1, sp[2].c1};
+            const int rc = run_group(ctx, w, a, nk, s);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+              if (!sp[0].c2.empty) {
+                ConvPlan b2[3] = {sp[0].c2, sp[1].c2, sp[2].c2};
+                const int rc2 = run_group(ctx, w, b2, nk, s);
+                if (rc2 < 0) return rc2;
+                if (rc2 != 0)
+                  for (int j = 0; j < nk; ++j) CHECK(run_plan(ctx, w, sp[j].c2, chn[j].st));
+              }
+              done = true;
             }
           }
-          ConvArgs a = base_args(rin, bs, ldo, d_frames, mul, tb, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
-          a.in_slope = 0.1f;
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
-          ConvArgs c = base_args(tb, bs, ldo, d_frames, mul, dst, bs, ldo, d_frames, mul, 1, (kk - 1) / 2);
-          c.in_slope = 0.1f;
-          c.res = rin;
-          if (last && !split_out) {
-            c.alpha = inv_nk;
-            c.accum = j > 0;
-          }
-          CHECK(launch_conv(ctx, w, rc.c2, c, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
-        } else {  // ResBlock2.forward, models.py:136-141
-          ConvArgs a = base_args(rin, bs, ldo, d_frames, mul, dst, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
-          a.in_slope = 0.1f;
-          a.res = rin;
-          if (last && !split_out) {
-            a.alpha = inv_nk;
-            a.accum = j > 0;
-          }
-          CHECK(launch_conv(ctx, w, rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, sj, rb_tiles, voc_host_len));
         }
-        rin = dst;
+        if (!done)
+          for (int j = 0; j < nk; ++j) CHECK(run_step_alone(j, sp[j]));
+        for (int j = 0; j < nk; ++j) chn[j].rin = sp[j].dst;
       }
+    } else {
+      // chain-major (the chains share their scratch planes and accumulate into one output)
+      for (int j = 0; j < nk; ++j)
+        for (int d = 0; d < nd; ++d) {
+          Step sp;
+          CHECK(plan_step(j, d, sp));
+          CHECK(run_step_alone(j, sp));
+          chn[j].rin = sp.dst;
+        }
     }
     if (concurrent) {
       for (int j = 1; j < nk; ++j) {

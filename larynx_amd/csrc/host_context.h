@@ -44,6 +44,7 @@ struct mi355tts_ctx {
   // call on ONE stream (the other calls fill the chip) instead of forking its MRF chains
   std::atomic<int> active_calls{0};
   bool adaptive_schedule = true;
+  bool mrf_group = true;  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;

@@ -86,10 +86,19 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   return fail(MI355TTS_ERR_INVALID, "paired epilogues run on 32-row tiles (MB == 1)");
 }
 
+// A conv launch, decided but not yet issued: arguments, tile shape and grid.
+struct ConvPlan {
+  ConvArgs a;
+  int K = 0, MB = 1, shape = TILE_TINY, epi = EPI_LINEAR, cls = 0;
+  dim3 grid;
+  double flop = 0;
+  bool empty = true;
+};
+
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
 // template instance.  n_max = largest GEMM-N extent over the batch rows.
-static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
-                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1) {
+static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls, int min_tiles, int host_len, ConvPlan* out) {
+  out->empty = true;
   if (n_max <= 0 || B <= 0) return 0;
   if (B == 1 && host_len >= 0) {
     // single utterance: the host already knows the row length, so the kernel need not
@@ -114,8 +123,7 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
   int ytiles = c.mtiles / MB;
   // Tile shape: the largest tile that still yields >= min_tiles workgroups, otherwise the
   // smallest tile.  1024 (4 per CU) is the measured sweet spot for a kernel that has the
-  // chip to itself (tools/conv_sweep.py); the three concurrent MRF chains ask for 300
-  // each — together they fill the chip, and the bigger tiles run closer to the MFMA rate.
+  // chip to itself (tools/conv_sweep.py).
   const int rows32 = (c.rows + 31) / 32;  // m-tiles when a workgroup is one m-tile high (the 128-column shape)
   auto tiles = [&](int width) { return (long long)((n_max + width - 1) / width) * (width == 128 ? rows32 : ytiles) * B; };
   const long long want = min_tiles;
@@ -144,52 +152,137 @@ static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs 
     ytiles = rows32;
   }
   const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
-  dim3 grid((n_max + T_T - 1) / T_T, ytiles, B);
-  const double flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
+  out->a = a;
+  out->K = c.K;
+  out->MB = MB;
+  out->shape = shape;
+  out->epi = epi;
+  out->cls = cls;
+  out->grid = dim3((n_max + T_T - 1) / T_T, ytiles, B);
+  out->flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
+  out->empty = false;
+  return 0;
+}
+
+static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t stream = nullptr) {
+  if (p.empty) return 0;
   hipStream_t s = stream ? stream : w->stream;
-  ProfScope ps(ctx, w, cls, flop, s);
+  ProfScope ps(ctx, w, p.cls, p.flop, s);
+  const ConvArgs& a = p.a;
+  const int MB = p.MB, shape = p.shape;
+  const dim3 grid = p.grid;
   int rc = 0;
-  if (epi == EPI_LINEAR) {
-    switch (c.K) {
+  if (p.epi == EPI_LINEAR) {
+    switch (p.K) {
       case 1: rc = launch_conv_k<1, EPI_LINEAR>(s, MB, shape, grid, a); break;
       case 3: rc = launch_conv_k<3, EPI_LINEAR>(s, MB, shape, grid, a); break;
       case 5: rc = launch_conv_k<5, EPI_LINEAR>(s, MB, shape, grid, a); break;
       case 7: rc = launch_conv_k<7, EPI_LINEAR>(s, MB, shape, grid, a); break;
       case 11: rc = launch_conv_k<11, EPI_LINEAR>(s, MB, shape, grid, a); break;
-      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d", c.K);
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d", p.K);
     }
-  } else if (epi == EPI_GATE) {
-    switch (c.K) {
+  } else if (p.epi == EPI_GATE) {
+    switch (p.K) {
       case 3: rc = launch_conv_k<3, EPI_GATE>(s, MB, shape, grid, a); break;
       case 5: rc = launch_conv_k<5, EPI_GATE>(s, MB, shape, grid, a); break;
-      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported WaveNet kernel size %d", c.K);
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported WaveNet kernel size %d", p.K);
     }
-  } else if (epi == EPI_COUPLING) {
-    if (c.K == 1) rc = launch_conv_k<1, EPI_COUPLING>(s, MB, shape, grid, a);
+  } else if (p.epi == EPI_COUPLING) {
+    if (p.K == 1) rc = launch_conv_k<1, EPI_COUPLING>(s, MB, shape, grid, a);
     else rc = fail(MI355TTS_ERR_INVALID, "coupling conv must be 1x1");
   } else {
-    switch (c.K) {
+    switch (p.K) {
       case 1: rc = launch_conv_k<1, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
       case 2: rc = launch_conv_k<2, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
       case 3: rc = launch_conv_k<3, EPI_UPSAMPLE>(s, MB, shape, grid, a); break;
-      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported upsample taps %d", c.K);
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported upsample taps %d", p.K);
     }
   }
   return rc;
 }
 
+static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
+                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1) {
+  ConvPlan p;
+  CHECK(plan_conv(c, a, epi, B, n_max, cls, min_tiles, host_len, &p));
+  return run_plan(ctx, w, p, stream);
+}
+
+// ---- grouped launch: the same-geometry convs of the MRF chains of a stage in ONE launch
+template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS>
+static void launch_group_inst(hipStream_t s, dim3 grid, const ConvGroupArgs& g) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, CI_C, MB, NB, WN, KS, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO>),
+                     grid, dim3(64 * WN * KS), 0, s, g);
+}
+template <int K0, int K1, int K2>
+static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvGroupArgs& g) {
+  // the tile shapes the batch-1 ... batch-8 ResBlock launches of the shipped vocoders use
+  if (shape == TILE_TINY && MB == 2) launch_group_inst<K0, K1, K2, 64, 2, 1, 1, 8>(s, grid, g);
+  else if (shape == TILE_TINY && MB == 1) launch_group_inst<K0, K1, K2, 64, 1, 1, 1, 8>(s, grid, g);
+  else if (shape == TILE_SMALL && MB == 2) launch_group_inst<K0, K1, K2, 32, 2, 1, 2, 4>(s, grid, g);
+  else if (shape == TILE_W128 && MB == 1) launch_group_inst<K0, K1, K2, 32, 1, 2, 2, 4>(s, grid, g);
+  else if (shape == TILE_NB2 && MB == 2) launch_group_inst<K0, K1, K2, 16, 2, 2, 4, 2>(s, grid, g);
+  else return 1;
+  return 0;
+}
+// Returns 0 = launched as one group, 1 = not groupable (caller launches the members one by one), < 0 = error.
+static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n, hipStream_t s) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GROUP"); return e && std::atoi(e) != 0; }();
+  if (off || n != 3) return 1;
+  // members ordered by tap count, longest-running first
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (plans[ord[j]].K > plans[ord[i]].K) std::swap(ord[i], ord[j]);
+  const ConvPlan& p0 = plans[ord[0]];
+  for (int i = 0; i < 3; ++i) {
+    const ConvPlan& p = plans[ord[i]];
+    if (p.empty || p.epi != EPI_LINEAR || p.shape != p0.shape || p.MB != p0.MB || p.grid.z != p0.grid.z) return 1;
+    if ((p.K - 1) * p.a.dil + ((4 - p.a.pad % 4) % 4) > (p.K == 3 ? 16 : p.K == 5 ? 28 : p.K == 7 ? 76 : p.K == 11 ? 56 : -1)) return 1;
+    if (p.a.x_ld % 4) return 1;
+  }
+  ConvGroupArgs g;
+  double flop = 0;
+  int off_wg = 0;
+  for (int i = 0; i < 3; ++i) {
+    const ConvPlan& p = plans[ord[i]];
+    g.c[i] = p.a;
+    g.gx[i] = (int)p.grid.x;
+    g.gy[i] = (int)p.grid.y;
+    g.off[i] = off_wg;
+    off_wg += ((int)(p.grid.x * p.grid.y) + 7) & ~7;
+    flop += p.flop;
+  }
+  g.off[3] = off_wg;
+  const dim3 grid(off_wg, 1, p0.grid.z);
+  const int k0 = plans[ord[0]].K, k1 = plans[ord[1]].K, k2 = plans[ord[2]].K;
+  const bool shape_ok = (p0.shape == TILE_TINY) || (p0.shape == TILE_SMALL && p0.MB == 2) || (p0.shape == TILE_W128 && p0.MB == 1) ||
+                        (p0.shape == TILE_NB2 && p0.MB == 2);
+  const bool taps_ok = (k0 == 11 && k1 == 7 && k2 == 3) || (k0 == 7 && k1 == 5 && k2 == 3);
+  if (!shape_ok || !taps_ok) return 1;
+  ProfScope ps(ctx, w, p0.cls, flop, s);
+  if (k0 == 11) return launch_group_k<11, 7, 3>(s, p0.MB, p0.shape, grid, g);
+  return launch_group_k<7, 5, 3>(s, p0.MB, p0.shape, grid, g);
+}
+
 // Fused ResBlock1 step (conv1 -> lrelu -> conv2 -> + x) for the 32/64-channel stages.
-// Returns 1 if the geometry is not covered (caller falls back to two conv launches).
-static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs,
-                       int ld, const int* len, int len_mul, int dil, float alpha, int accum, int B, int Lmax, hipStream_t s,
-                       int host_len = -1) {
+struct PairPlan {
+  PairArgs a;
+  int K = 0, C = 0, NB = 1;
+  dim3 grid;
+  double flop = 0;
+  bool ok = false;  // geometry covered by the fused kernel
+};
+static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs, int ld, const int* len,
+                      int len_mul, int dil, float alpha, int accum, int B, int Lmax, int host_len, PairPlan* out) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
   const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
+  out->ok = false;
   if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
-      (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y)
-    return 1;
-  PairArgs a;
+      (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y || Lmax <= 0)
+    return;
+  PairArgs& a = out->a;
   a.x = x;
   a.y = y;
   a.bs = bs;
@@ -207,21 +300,61 @@ static int launch_pair(mi355tts_ctx* ctx, Worker* w, const DevConv& c1, const De
   a.slope = 0.1f;
   a.alpha = alpha;
   a.accum = accum;
-  const int NB = (C == 32) ? 2 : nb64;
-  const int T2 = 128 * NB - (K - 1);
-  dim3 grid((Lmax + T2 - 1) / T2, 1, B);
-  const double flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
-  ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+  out->K = K;
+  out->C = C;
+  out->NB = (C == 32) ? 2 : nb64;
+  const int T2 = 128 * out->NB - (K - 1);
+  out->grid = dim3((Lmax + T2 - 1) / T2, 1, B);
+  out->flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
+  out->ok = true;
+}
+static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t s) {
+  ProfScope ps(ctx, w, KC_RESBLOCK, p.flop, s);
+  const PairArgs& a = p.a;
+  const dim3 grid = p.grid;
 #define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
 #define PAIR_K(KK)                                  \
-  if (C == 32) PAIR_LAUNCH(KK, 1, 2);               \
-  else if (NB == 2) PAIR_LAUNCH(KK, 2, 2);          \
+  if (p.C == 32) PAIR_LAUNCH(KK, 1, 2);             \
+  else if (p.NB == 2) PAIR_LAUNCH(KK, 2, 2);        \
   else PAIR_LAUNCH(KK, 2, 1)
-  if (K == 3) { PAIR_K(3); }
-  else if (K == 7) { PAIR_K(7); }
+  if (p.K == 3) { PAIR_K(3); }
+  else if (p.K == 7) { PAIR_K(7); }
   else { PAIR_K(11); }
 #undef PAIR_K
 #undef PAIR_LAUNCH
+  return 0;
+}
+// The three chains' fused steps as ONE launch (k = 11, 7, 3 members).  0 = launched, 1 = not groupable.
+static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, int n, hipStream_t s) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GROUP"); return e && std::atoi(e) != 0; }();
+  if (off || n != 3) return 1;
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (plans[ord[j]].K > plans[ord[i]].K) std::swap(ord[i], ord[j]);
+  const PairPlan& p0 = plans[ord[0]];
+  for (int i = 0; i < 3; ++i) {
+    const PairPlan& p = plans[ord[i]];
+    if (!p.ok || p.C != p0.C || p.NB != p0.NB || p.grid.z != p0.grid.z) return 1;
+  }
+  if (!(plans[ord[0]].K == 11 && plans[ord[1]].K == 7 && plans[ord[2]].K == 3)) return 1;
+  if (!((p0.C == 32 && p0.NB == 2) || (p0.C == 64 && p0.NB == 1))) return 1;
+  PairGroupArgs g;
+  double flop = 0;
+  int off_wg = 0;
+  for (int i = 0; i < 3; ++i) {
+    const PairPlan& p = plans[ord[i]];
+    g.p[i] = p.a;
+    g.gx[i] = (int)p.grid.x;
+    g.off[i] = off_wg;
+    off_wg += ((int)p.grid.x + 7) & ~7;
+    flop += p.flop;
+  }
+  g.off[3] = off_wg;
+  const dim3 grid(off_wg, 1, p0.grid.z);
+  ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+  if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 1, 2>), grid, dim3(512), 0, s, g);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 2, 1>), grid, dim3(512), 0, s, g);
   return 0;
 }
 

@@ -912,6 +912,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->adaptive_schedule = value != 0;
     return 0;
   }
+  if (std::strcmp(name, "mrf_group") == 0) {
+    ctx->mrf_group = value != 0;
+    return 0;
+  }
   if (std::strcmp(name, "serial_branches") == 0) {
     ctx->serial_branches = value != 0;
     return 0;

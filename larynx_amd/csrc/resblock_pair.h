@@ -102,22 +102,29 @@ __device__ __forceinline__ void pair_mfma_phase(floatx16 (&acc)[CB][NB], const f
 }
 
 template <int K, int CB, int NB>
-__global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
+struct PairGeom {
+  static constexpr int C = CB * 32;
+  static constexpr int T1 = 4 * NB * 32;                                 // conv1 columns per workgroup
+  static constexpr int XW = (T1 + (K - 1) * PAIR_DMAX + 4 + 3) & ~3;     // staged x row: tile + conv1 halo + alignment slack
+  static constexpr int TW = (T1 + K + 3) & ~3;                           // parked conv1 row (+ slack for the masked tail reads)
+  static constexpr int XS = C * XW, TS = C * TW;                         // LDS floats
+};
+
+// One workgroup's tile: output columns [tile_x * T2, +T2) of batch row b.  xs / ts = PairGeom::XS / TS floats of LDS.
+template <int K, int CB, int NB>
+__device__ __forceinline__ void pair_tile(const PairArgs& a, const int tile_x, const int b, float* __restrict__ xs, float* __restrict__ ts) {
   constexpr int C = CB * 32;
   constexpr int WN = 4;
   constexpr int T1 = WN * NB * 32;     // conv1 columns per workgroup
   constexpr int P2 = (K - 1) / 2;      // conv2 "same" padding
   constexpr int T2 = T1 - 2 * P2;      // output columns per workgroup
-  constexpr int XW = (T1 + (K - 1) * PAIR_DMAX + 4 + 3) & ~3;  // staged x row: tile + conv1 halo + alignment slack
-  constexpr int TW = (T1 + K + 3) & ~3;                        // parked conv1 row (+ slack for the masked tail reads)
+  constexpr int XW = PairGeom<K, CB, NB>::XW;
+  constexpr int TW = PairGeom<K, CB, NB>::TW;
   constexpr int NO = (C / 8) / 2;      // octets per k-group
   constexpr int NF4 = C * (XW / 4);
   constexpr int NE = (NF4 + 511) / 512;
   constexpr int RED = WN * NB * 16 * 64;  // one m-block of every time-wave
   static_assert(C * XW >= RED, "reduction scratch must fit in the x tile");
-
-  __shared__ float xs[C * XW];
-  __shared__ float ts[C * TW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,10 +133,7 @@ __global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
   const int kg = wave >> 2;
   const int col = lane & 31, half = lane >> 5;
   const int rbase = 4 * half;
-  const int b = blockIdx.z;
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
-  int tile_x, tile_y;
-  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
   const int j0 = tile_x * T2;  // first output column of this workgroup
   if (j0 >= L) return;
   const int gt0 = j0 - P2;                  // global column of parked-tile column 0
@@ -275,6 +279,52 @@ __global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
       for (int r = 0; r < 16; ++r)
         if (tok) yb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld] = v[r];
     }
+  }
+}
+
+template <int K, int CB, int NB>
+__global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
+  __shared__ float xs[PairGeom<K, CB, NB>::XS];
+  __shared__ float ts[PairGeom<K, CB, NB>::TS];
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
+  pair_tile<K, CB, NB>(a, tile_x, blockIdx.z, xs, ts);
+}
+
+// The fused steps of the three MRF chains of a stage in ONE launch (see conv_group_kernel): the
+// first off[1] workgroups are member 0's tiles (largest K first), then member 1's, then member 2's.
+struct PairGroupArgs {
+  PairArgs p[3];
+  int gx[3];
+  int off[4];
+};
+template <int K0, int K1, int K2, int CB, int NB>
+__global__ __launch_bounds__(512) void pair_group_kernel(const PairGroupArgs g) {
+  constexpr int XS = PairGeom<K0, CB, NB>::XS > PairGeom<K1, CB, NB>::XS
+                         ? (PairGeom<K0, CB, NB>::XS > PairGeom<K2, CB, NB>::XS ? PairGeom<K0, CB, NB>::XS : PairGeom<K2, CB, NB>::XS)
+                         : (PairGeom<K1, CB, NB>::XS > PairGeom<K2, CB, NB>::XS ? PairGeom<K1, CB, NB>::XS : PairGeom<K2, CB, NB>::XS);
+  constexpr int TS = PairGeom<K0, CB, NB>::TS > PairGeom<K1, CB, NB>::TS
+                         ? (PairGeom<K0, CB, NB>::TS > PairGeom<K2, CB, NB>::TS ? PairGeom<K0, CB, NB>::TS : PairGeom<K2, CB, NB>::TS)
+                         : (PairGeom<K1, CB, NB>::TS > PairGeom<K2, CB, NB>::TS ? PairGeom<K1, CB, NB>::TS : PairGeom<K2, CB, NB>::TS);
+  __shared__ float xs[XS];
+  __shared__ float ts[TS];
+  const int lin = blockIdx.x;
+  const int b = blockIdx.z;
+  int tx, ty;
+  if (lin < g.off[1]) {
+    if (lin >= g.gx[0]) return;
+    xcd_tile_lin(lin, g.gx[0], 1, tx, ty);
+    pair_tile<K0, CB, NB>(g.p[0], tx, b, xs, ts);
+  } else if (lin < g.off[2]) {
+    const int l = lin - g.off[1];
+    if (l >= g.gx[1]) return;
+    xcd_tile_lin(l, g.gx[1], 1, tx, ty);
+    pair_tile<K1, CB, NB>(g.p[1], tx, b, xs, ts);
+  } else {
+    const int l = lin - g.off[2];
+    if (l >= g.gx[2]) return;
+    xcd_tile_lin(l, g.gx[2], 1, tx, ty);
+    pair_tile<K2, CB, NB>(g.p[2], tx, b, xs, ts);
   }
 }
 

@@ -181,3 +181,51 @@ def test_device_noise_is_standard_normal(emu_engine):
     from tests.noise_check import check_gauss_noise
 
     check_gauss_noise(emu_engine, 2, 16, 4000, ks_bound=1.95 / np.sqrt(2 * 16 * 4000))
+
+
+def check_grouped_schedule(eng, hp, seed, frames):
+    """Three MRF chains: the default schedule issues the same-geometry launches of a step as ONE
+    grouped launch (conv_group_kernel / pair_group_kernel); the forked / one-by-one schedules must
+    give the same bits, and all of them the oracle's waveform."""
+    sd = synthetic.make_hifigan_state_dict(hp, seed=seed)
+    v = eng.load_hifigan(hp, sd)
+    rng = np.random.default_rng(seed + 1)
+    fr = np.asarray(frames, np.int32)
+    melin = (rng.standard_normal((len(fr), hp.num_mels, int(fr.max()))) * 2).astype(np.float32)
+    mb = eng.mel_from_numpy(melin, fr)
+    eng.set_profiling(True)
+    eng.profile_reset()
+    grouped, _ = eng.hifigan_infer(v, mb)
+    n_grouped = eng.profile()["conv_mfma.hifigan_resblock"]["launches"]
+    eng.set_option("mrf_group", 0)
+    eng.profile_reset()
+    try:
+        forked, _ = eng.hifigan_infer(v, mb)
+        n_forked = eng.profile()["conv_mfma.hifigan_resblock"]["launches"]
+        eng.set_option("adaptive_schedule", 0)
+        forked2, _ = eng.hifigan_infer(v, mb)
+    finally:
+        eng.set_option("mrf_group", 1)
+        eng.set_option("adaptive_schedule", 1)
+        eng.set_profiling(False)
+    assert np.array_equal(grouped, forked) and np.array_equal(grouped, forked2)
+    assert n_forked == 3 * n_grouped, (n_forked, n_grouped)  # every step of the three chains became one launch
+    for b in range(len(fr)):
+        ref = hifi_gan_np.hifigan_infer(sd, hp, melin[b, :, : fr[b]])
+        n = fr[b] * hp.hop
+        assert np.sqrt(np.mean((grouped[b, :n] - ref) ** 2)) < 1e-5
+        assert np.all(grouped[b, n:] == 0)
+    eng.unload(v)
+
+
+def test_grouped_mrf_launches_resblock1(emu_engine):
+    # stages of 128 channels (un-fused convs -> conv_group_kernel) and 64 channels (fused pairs -> pair_group_kernel)
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    check_grouped_schedule(emu_engine, hp, 71, [23, 17])
+
+
+def test_grouped_mrf_launches_resblock2(emu_engine):
+    hp = HP.HifiGanHParams(resblock="2", upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=64,
+                           resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)), num_mels=16)
+    check_grouped_schedule(emu_engine, hp, 73, [19])
