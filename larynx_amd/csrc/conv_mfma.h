@@ -101,6 +101,9 @@ struct ConvArgs {
   // (tools/conv_probe.py; results are WRONG when set): bit0 = no activation staging after
   // chunk 0, bit1 = no A-fragment loads after the prologue, bit2 = no per-chunk barrier
   int ablate;
+  // workgroup -> tile order inside an XCD's run: 0 = row tile fastest (tiles of one time tile share their
+  // input in one L2), 1 = time tile fastest (an XCD owns a range of row tiles = a slice of the weights)
+  int rows_major;
 };
 
 // XCD-aware tile order.  The dispatcher deals workgroup `lin` to XCD `lin % 8`, each XCD
@@ -108,16 +111,26 @@ struct ConvArgs {
 // neighbouring time tiles through the halo) should meet in ONE L2, so the linear id is
 // re-dealt: XCD x gets a contiguous run of tiles, m-tile fastest.  Bijective for any n
 // (MI355X_MICROARCH.md, T1); a wrong placement guess costs speed, never correctness.
-__device__ __forceinline__ void xcd_tile_lin(int lin, int gx, int gy, int& tx, int& ty) {
+//
+// `rows_major` != 0 flips the order inside the run: XCD x then owns a contiguous range of ROW tiles (with all
+// their time tiles), i.e. 1/8 of the weights — for launches whose packed weights do not fit one 4 MB L2 while
+// their input does (the stage-0 upsampler of HiFi-GAN 'high': 8.4 MB of weights, 1.3 MB of input; with time
+// dealt across the XCDs every XCD streamed all 8.4 MB once per time tile: 86 MB fetched per launch).
+__device__ __forceinline__ void xcd_tile_lin(int lin, int gx, int gy, int& tx, int& ty, int rows_major = 0) {
   const int n = gx * gy;
   const int xcd = lin & 7, slot = lin >> 3;
   const int q = n >> 3, r = n & 7;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  ty = id % gy;
-  tx = id / gy;
+  if (rows_major) {
+    tx = id % gx;
+    ty = id / gx;
+  } else {
+    ty = id % gy;
+    tx = id / gy;
+  }
 }
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
-  xcd_tile_lin(blockIdx.x + blockIdx.y * gx, gx, gy, tx, ty);
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty, int rows_major = 0) {
+  xcd_tile_lin(blockIdx.x + blockIdx.y * gx, gx, gy, tx, ty, rows_major);
 }
 
 // LDS floats one workgroup of a tile shape needs (staging double buffer, reused by the k-group reduction)
@@ -730,7 +743,7 @@ template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
 __global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
   __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI>()];
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
   conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 

@@ -152,6 +152,15 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     ytiles = rows32;
   }
   const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  // Which operand the 8 XCD L2s replicate: dealing TIME tiles across the XCDs makes every L2 fetch all the
+  // weights (8 W + X bytes from memory, and W must fit 4 MB or it is re-streamed per time tile); dealing ROW
+  // tiles makes every L2 fetch the whole input and 1/8 of the weights (W + 8 X).  Rows when the weights are
+  // the bigger operand and the input fits an L2 (GlowTTS launches, conv_pre, the stage-0 upsampler).
+  {
+    const double w_bytes = (double)c.mtiles * c.noct * c.K * 1024.0;
+    const double x_bytes = (double)c.Cin * (double)n_max * 4.0 * B;
+    a.rows_major = (w_bytes > x_bytes && x_bytes < 3.0e6 && ytiles >= 8) ? 1 : 0;
+  }
   out->a = a;
   out->K = c.K;
   out->MB = MB;

@@ -32,7 +32,7 @@ def test_bench_line_at_world_size(emu_library_path, gpus):
     assert abs(out["value"] - gpus * 3 / (out["ms_per_step"] * 3 / 1e3)) < 1e-6 * out["value"]
     assert out["config"]["parallelism"] == f"utterance-dp{gpus}" and out["config"]["batch"] == 1
     rf = out["roofline"]
-    assert rf["bound"] == "mfma" and rf["launches"] > 0 and "serial_branches" in rf["schedule"]
+    assert rf["bound"] == "mfma" and rf["launches"] > 0 and "grouped launch" in rf["schedule"]
     c3 = out["config3"]
     assert c3["utterances"] == 7 and c3["scaling"] == "strong" and sum(c3["shard_sizes"]) == 7 and len(c3["shard_sizes"]) == gpus
     assert c3["utterances_per_sec"] > 0 and c3["audio_seconds"] > 0
