@@ -722,6 +722,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
       for (int nb = 0; nb < NB; ++nb) {
         const int q = t0 + (wn * NB + nb) * 32 + col;
         if (q >= n_len) continue;
+        if ((a.up & 3) == 0 && (a.up_pad & 3) == 0 && (a.y_ld & 3) == 0) {
+          // registers 4g..4g+3 of a lane are 4 consecutive virtual rows = 4 consecutive phases of ONE output
+          // channel = 4 consecutive, 16-byte aligned output samples: one float4 store instead of four scalar
+          // stores 4*up bytes apart (the two half-waves fill the other phases of the same 32-byte runs)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int row0 = (mt0 + mb) * 32 + 8 * g4 + rbase;
+            if (row0 >= a.rows) continue;
+            const int co = row0 / a.up;
+            const int n0 = q * a.up + (row0 - co * a.up) - a.up_pad;
+            float* dst = a.y + (long long)b * a.y_bs + (long long)co * a.y_ld + n0;
+            if (n0 >= 0 && n0 + 3 < Lout) {
+              *reinterpret_cast<float4*>(dst) = make_float4(acc[mb][nb][4 * g4] + bb[4 * g4], acc[mb][nb][4 * g4 + 1] + bb[4 * g4 + 1],
+                                                            acc[mb][nb][4 * g4 + 2] + bb[4 * g4 + 2], acc[mb][nb][4 * g4 + 3] + bb[4 * g4 + 3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n0 + e >= 0 && n0 + e < Lout) dst[e] = acc[mb][nb][4 * g4 + e] + bb[4 * g4 + e];
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;

@@ -55,6 +55,15 @@ def emu_engine(emu_library):
 
 @pytest.fixture(scope="session")
 def gpu_engine():
+    # torch wheels carry their own HIP runtime: when a process uses both, torch's must come up first
+    # (INTEGRATION.md "Sharing a process with PyTorch"); some gpu tests hand torch tensors to the library
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from larynx_amd.engine import Engine
 
     eng = Engine(device=0)
