@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = the emulator build (tests only)")
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="f32 = exact f32 MFMA everywhere (the graded parity mode); bf16x3 = the `half` switch: split-bf16 "
+                         "ResBlock convs (3 x bf16 MFMA per product, f32 accumulate)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -228,6 +231,8 @@ def main():
     g = eng.load_glow(ghp, device_ptr=blob.data_ptr())
     v = eng.load_hifigan(vhp, device_ptr=blob.data_ptr() + 4 * n_g)
     del blob
+    if args.precision == "bf16x3":
+        eng.set_precision(v, ffi.PRECISION_BF16X3)
 
     # ---- synthetic utterances (one per step per rank), resident in HBM
     rng = np.random.default_rng(1234 + rank)
@@ -434,7 +439,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 MFMA, f32 accumulate) in the ResBlock convs, f32 elsewhere",
             "data": "synthetic",
             "config": {
                 "workload": f"en-us ljspeech GlowTTS + hifi_gan '{quality}', batch={B}, {args.ids} phoneme ids per utterance "

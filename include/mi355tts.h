@@ -104,6 +104,16 @@ int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams* hp, const
 int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_hparams* hp, const float* blob, int64_t numel,
                           int on_device, int* model_out);
 int mi355tts_unload(mi355tts_ctx* ctx, int model);
+/* The reference's `half` switch (TextToSpeechModelConfig.half / VocoderModelConfig.half,
+ * larynx/constants.py:58,85; `.half()` at larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97).
+ * MI355TTS_PRECISION_F32 (default): exact f32 MFMA everywhere — the parity mode.
+ * MI355TTS_PRECISION_BF16X3: the HiFi-GAN ResBlock convs with >= 64 channels (93 % of the path's
+ * FLOPs) run on the bf16 matrix cores with split operands (x = hi + lo, three bf16 MFMAs per
+ * product, f32 accumulate): ~1e-5 relative error per layer instead of exact f32.  GlowTTS models
+ * accept the call and keep computing in f32. */
+#define MI355TTS_PRECISION_F32 0
+#define MI355TTS_PRECISION_BF16X3 1
+int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision);
 
 /* ---- GlowTTS: replaces GlowTextToSpeech.phonemes_to_mels --------------------
  * ids [B][ids_ld] int64 (row b valid for id_lens[b] entries; the reference's

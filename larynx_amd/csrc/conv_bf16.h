@@ -1,0 +1,303 @@
+// conv1d as an implicit GEMM on the CDNA4 bf16 matrix cores with SPLIT operands — the
+// reduced-precision mode behind the reference's `half` switch (larynx/glow_tts.py:90-91,
+// larynx/hifi_gan.py:96-97, README "--half"), SURVEY.md §8(f) rank 4.
+//
+// Every f32 operand x is split on the fly into two bf16 numbers, x = hi + lo + O(2^-17 |x|)
+// (hi = bf16(x), lo = bf16(x - hi)), and a product is formed from three bf16 MFMAs accumulated in
+// f32:   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi        (the dropped terms are O(2^-16 |a b|)).
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32 MFMA the exact path uses
+// (MI355X_MICROARCH.md: ~2.5 PFLOP/s dense vs 157 TFLOP/s), so three of them still leave 5.3x the
+// matrix rate — the kernel is bound by operand delivery (LDS reads, the weight stream), not by
+// the matrix pipe.  Accuracy: ~1e-5 relative per layer, i.e. far better than the fp16 tensors
+// of the reference's `--half` (11-bit mantissa everywhere, no f32 accumulate guarantee).
+//
+//   y[co][t] = [y +] alpha * (bias[co] + res[co][t] + sum_{ci,k} W[co][ci][k] * lrelu(x[ci][t + k*dil - pad]))
+//
+// GEMM view as in conv_mfma.h: M = output channels (A = weights, pre-split and pre-packed in fragment
+// order, streamed L2 -> VGPR 16 B per lane), N = time (B = activations, split once per element while
+// they are staged into LDS in an [octet][column][8 channels] bf16 layout, so one B fragment — 8
+// consecutive channels of one column — is ONE aligned ds_read_b128), K-dim = (16-channel slab, tap).
+// One workgroup = WM x WN waves; a wave owns MB x NB blocks of 32 x 32 over ALL input channels
+// (no k-split: 16-deep MFMAs make the per-wave work large enough).  Used for the HiFi-GAN ResBlock
+// convs (hifi_gan/models.py:91-98, 136-141) when the vocoder was switched to this mode.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_mfma.h"
+
+namespace mi355tts {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> two bf16 (round to nearest even), first argument in the low half
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2 p = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, p);
+}
+// hi/lo split of two floats: x = hi + lo + O(2^-17 |x|)
+__device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+  lo = pack_bf16(a - ah, b - bh);
+}
+__device__ __forceinline__ floatx16 mfma_bf16(const uint4& a, const uint4& b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// LDS of one workgroup, in uint4 (16-byte) units: two buffers x {hi, lo} x 4 octets x XW columns
+template <int NB, int WN, int HALO>
+constexpr int conv_bf16_lds_units() {
+  return 2 * 2 * 4 * (32 * NB * WN + HALO);
+}
+
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS>
+__device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, uint4* __restrict__ xs) {
+  constexpr int NWAVES = WM * WN;
+  constexpr int NT = 64 * NWAVES;
+  constexpr int T_T = 32 * NB * WN;   // time columns per workgroup
+  constexpr int XW = T_T + HALO;      // staged columns per octet row
+  constexpr int XQ = XW / 4;          // column quads
+  constexpr int OCT = 4;              // 32 input channels per staged chunk = 2 MFMA slabs of 16
+  constexpr int PLANE = OCT * XW;     // uint4 units per plane (hi or lo)
+  constexpr int BUF = 2 * PLANE;      // per buffer
+  constexpr int NUNITS = OCT * XQ;    // staging units (octet, column quad) per chunk
+  constexpr int NU = (NUNITS + NT - 1) / NT;
+  static_assert(XW % 4 == 0 && (TERMS == 1 || TERMS == 3), "bad tile parameters");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+  const int t0 = tile_x * T_T;
+  const int mt0 = (tile_y * WM + wm) * MB;
+
+  const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
+  const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
+  if (t0 >= Lout) return;  // uniform per workgroup
+
+  const float slope = a.in_slope;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int nchunks = (a.Cin + 31) / 32;
+  const int PA = (a.pad + 3) & ~3;
+  const int cin_last = a.Cin - 1;
+  const int ld_last4 = a.x_ld - 4;
+
+  // ---- staging: unit (octet o, column quad q) = 8 channels x 4 columns, eight 16-byte loads (one per
+  // channel, coalesced along time), split into bf16 hi/lo and stored column by column as 16-byte
+  // [8 channels] groups.  The loads of chunk c+1 are issued before chunk c's MFMA phase and consumed after it.
+  float4 pre[NU][8];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = tid + NT * i;
+      const int o = u < NUNITS ? u / XQ : 0, q = u < NUNITS ? u - (u / XQ) * XQ : 0;
+      const int c0 = t0 - PA + 4 * q;
+      const int cc = c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = chunk * 32 + 8 * o + j;
+        pre[i][j] = *reinterpret_cast<const float4*>(xb + (long long)(ci < a.Cin ? ci : cin_last) * a.x_ld + cc);
+      }
+    }
+  };
+  auto lstore = [&](int buf, int chunk) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = tid + NT * i;
+      if (u >= NUNITS) continue;
+      const int o = u / XQ, q = u - o * XQ;
+      const int c0 = t0 - PA + 4 * q;
+      float v[8][4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool cok = chunk * 32 + 8 * o + j < a.Cin;
+        const float4 p = pre[i][j];
+        v[j][0] = (cok && c0 >= 0 && c0 < Lin) ? p.x : 0.f;
+        v[j][1] = (cok && c0 + 1 >= 0 && c0 + 1 < Lin) ? p.y : 0.f;
+        v[j][2] = (cok && c0 + 2 >= 0 && c0 + 2 < Lin) ? p.z : 0.f;
+        v[j][3] = (cok && c0 + 3 >= 0 && c0 + 3 < Lin) ? p.w : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * slope;
+      }
+      uint4* dst = xs + buf * BUF + o * XW + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint4 hi, lo;
+        split_bf16(v[0][e], v[1][e], hi.x, lo.x);
+        split_bf16(v[2][e], v[3][e], hi.y, lo.y);
+        split_bf16(v[4][e], v[5][e], hi.z, lo.z);
+        split_bf16(v[6][e], v[7][e], hi.w, lo.w);
+        dst[e] = hi;
+        dst[PLANE + e] = lo;
+      }
+    }
+  };
+
+  floatx16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // A stream of m-tile mt: uint4 index (((mt*nslab + slab)*K + k)*2 + plane)*64 + lane
+  const uint4* wq[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) wq[mb] = reinterpret_cast<const uint4*>(a.w16) + (long long)(mt0 + mb) * a.nslab * K * 128 + lane;
+  constexpr int S = 2 * K;  // steps per chunk: tap-major, two slabs per tap
+  const int last_step = nchunks * S - 1;
+  auto a_off = [&](int g) -> int {  // uint4 offset of global step g (clamped at the end: harmless re-load)
+    g = g < last_step ? g : last_step;
+    const int ch = g / S, st = g - ch * S;
+    const int k = st >> 1, s = st & 1;
+    return ((ch * 2 + s) * K + k) * 128;
+  };
+  uint4 Ahi[MB], Alo[MB], Nhi[MB], Nlo[MB];
+
+  gload(0);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    Ahi[mb] = wq[mb][a_off(0)];
+    Alo[mb] = wq[mb][a_off(0) + 64];
+  }
+  lstore(0, 0);
+  __syncthreads();
+
+  // this lane's B column inside the staged row, and its octet half
+  const int colb = wn * (NB * 32) + (lane & 31) + (PA - a.pad);
+  const int ohalf = lane >> 5;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    const bool more = chunk + 1 < nchunks;
+    if (more) gload(chunk + 1);
+    const uint4* xt = xs + buf * BUF + colb;
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      const int k = st >> 1, s = st & 1;
+      // next step's weight fragments go out first, this step's operands are already in registers
+      {
+        const int off = a_off(chunk * S + st + 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          Nhi[mb] = wq[mb][off];
+          if (TERMS == 3) Nlo[mb] = wq[mb][off + 64];
+        }
+      }
+      uint4 Bhi[NB], Blo[NB];
+      const uint4* bp = xt + (2 * s + ohalf) * XW + k * a.dil;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        Bhi[nb] = bp[nb * 32];
+        if (TERMS == 3) Blo[nb] = bp[PLANE + nb * 32];
+      }
+      // term-major order: consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ahi[mb], Bhi[nb], acc[mb][nb]);
+      if (TERMS == 3) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ahi[mb], Blo[nb], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Alo[mb], Bhi[nb], acc[mb][nb]);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        Ahi[mb] = Nhi[mb];
+        if (TERMS == 3) Alo[mb] = Nlo[mb];
+      }
+    }
+    if (more) lstore(buf ^ 1, chunk + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual, scale, accumulate; loads batched from clamped addresses
+  const int col = lane & 31;
+  const int rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float bb[16];
+    int roff[16];
+    bool rok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+      rok[r] = row < a.rows;
+      bb[r] = (a.bias && rok[r]) ? a.bias[row] : 0.f;
+      roff[r] = (rok[r] ? row : a.rows - 1) * a.y_ld;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int t = t0 + (wn * NB + nb) * 32 + col;
+      const bool tok = t < Lout;
+      const int tc = tok ? t : Lout - 1;
+      float* yb = a.y + (long long)b * a.y_bs + tc;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[mb][nb][r] + bb[r];
+      if (a.res) {
+        const float* rb = a.res + (long long)b * a.y_bs + tc;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = rb[roff[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] *= a.alpha;
+      if (a.accum) {
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = yb[roff[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += ov[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rok[r] && tok) yb[roff[r]] = v[r];
+    }
+  }
+}
+
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const ConvArgs a) {
+  __shared__ uint4 xs[conv_bf16_lds_units<NB, WN, HALO>()];
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
+  conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS>(a, tile_x, tile_y, blockIdx.z, xs);
+}
+
+// The three MRF chains' same-geometry convs in ONE launch (see conv_group_kernel).
+template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int TERMS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_group_kernel(const ConvGroupArgs g) {
+  constexpr int L0 = conv_bf16_lds_units<NB, WN, H0>(), L1 = conv_bf16_lds_units<NB, WN, H1>(), L2 = conv_bf16_lds_units<NB, WN, H2>();
+  __shared__ uint4 xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
+  const int lin = blockIdx.x;
+  const int b = blockIdx.z;
+  int tx, ty;
+  if (lin < g.off[1]) {
+    if (lin >= g.gx[0] * g.gy[0]) return;
+    xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
+    conv_bf16_tile<K0, MB, NB, WM, WN, H0, TERMS>(g.c[0], tx, ty, b, xs);
+  } else if (lin < g.off[2]) {
+    const int l = lin - g.off[1];
+    if (l >= g.gx[1] * g.gy[1]) return;
+    xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
+    conv_bf16_tile<K1, MB, NB, WM, WN, H1, TERMS>(g.c[1], tx, ty, b, xs);
+  } else {
+    const int l = lin - g.off[2];
+    if (l >= g.gx[2] * g.gy[2]) return;
+    xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
+    conv_bf16_tile<K2, MB, NB, WM, WN, H2, TERMS>(g.c[2], tx, ty, b, xs);
+  }
+}
+
+}  // namespace mi355tts

@@ -104,6 +104,9 @@ struct ConvArgs {
   // workgroup -> tile order inside an XCD's run: 0 = row tile fastest (tiles of one time tile share their
   // input in one L2), 1 = time tile fastest (an XCD owns a range of row tiles = a slice of the weights)
   int rows_major;
+  // split-bf16 mode (conv_bf16.h): the same weights as bf16 hi/lo fragments, and their slab count
+  const void* w16;
+  int nslab;
 };
 
 // XCD-aware tile order.  The dispatcher deals workgroup `lin` to XCD `lin % 8`, each XCD

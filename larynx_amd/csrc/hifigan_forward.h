@@ -197,6 +197,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
   const int rb_tiles = rb_env > 0 ? rb_env : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
+  const int prec = hm->precision.load();
   const int pads = call.pad_before + call.pad_after;
   const HifiLayout lay = hifi_layout(h, hop, B, F, denoise, split_out, pads);
   const size_t Nld = lay.Nld;
@@ -295,11 +296,11 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
       sp.pair.ok = false;
       if (h.resblock_type == 1) {  // ResBlock1.forward, models.py:91-98
         plan_pair(rc.c1, rc.c2, c.rin, sp.dst, bs, ldo, d_frames, mul, rc.dil, fold ? inv_nk : 1.0f, fold ? (j > 0) : 0, B, Lout,
-                  voc_host_len, &sp.pair);
+                  voc_host_len, &sp.pair, prec);
         if (sp.pair.ok) return 0;
         ConvArgs a = base_args(c.rin, bs, ldo, d_frames, mul, c.tb, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
         a.in_slope = 0.1f;
-        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1));
+        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1, prec));
         ConvArgs c2 = base_args(c.tb, bs, ldo, d_frames, mul, sp.dst, bs, ldo, d_frames, mul, 1, (kk - 1) / 2);
         c2.in_slope = 0.1f;
         c2.res = c.rin;
@@ -307,7 +308,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
           c2.alpha = inv_nk;
           c2.accum = j > 0;
         }
-        CHECK(plan_conv(rc.c2, c2, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c2));
+        CHECK(plan_conv(rc.c2, c2, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c2, prec));
       } else {  // ResBlock2.forward, models.py:136-141
         ConvArgs a = base_args(c.rin, bs, ldo, d_frames, mul, sp.dst, bs, ldo, d_frames, mul, rc.dil, (kk * rc.dil - rc.dil) / 2);
         a.in_slope = 0.1f;
@@ -316,7 +317,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
           a.alpha = inv_nk;
           a.accum = j > 0;
         }
-        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1));
+        CHECK(plan_conv(rc.c1, a, EPI_LINEAR, B, Lout, KC_RESBLOCK, rb_tiles, voc_host_len, &sp.c1, prec));
         sp.c2.empty = true;
       }
       return 0;

@@ -93,12 +93,22 @@ struct ConvPlan {
   dim3 grid;
   double flop = 0;
   bool empty = true;
+  int bf16 = 0;  // 0 = f32 kernel; 3 = split-bf16 kernel (conv_bf16.h), `shape` is then a Bf16Cfg
+};
+
+// Tile configurations of the split-bf16 kernel (all 4 waves; a wave owns 1 x NB blocks over all input channels)
+enum Bf16Cfg {
+  BF_A = 0,  // 4 x 1 waves, NB = 4: 128 rows x 128 columns
+  BF_B = 1,  // 4 x 1 waves, NB = 2: 128 rows x  64 columns (few-tile launches)
+  BF_C = 2,  // 2 x 2 waves, NB = 2:  64 rows x 128 columns (64-channel stages)
 };
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
 // template instance.  n_max = largest GEMM-N extent over the batch rows.
-static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls, int min_tiles, int host_len, ConvPlan* out) {
+static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls, int min_tiles, int host_len, ConvPlan* out,
+                     int precision = 0) {
   out->empty = true;
+  out->bf16 = 0;
   if (n_max <= 0 || B <= 0) return 0;
   if (B == 1 && host_len >= 0) {
     // single utterance: the host already knows the row length, so the kernel need not
@@ -119,6 +129,35 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   a.noct = c.noct;
   a.Cin = c.Cin;
   a.rows = c.rows;
+  if (precision == MI355TTS_PRECISION_BF16X3 && c.w16 && epi == EPI_LINEAR && !a.x2 && !a.y2 && a.split >= c.rows && a.out_act == ACT_NONE &&
+      (c.K == 3 || c.K == 5 || c.K == 7 || c.K == 11) && (a.x_ld % 4) == 0 &&
+      (c.K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= (c.K == 3 ? 16 : c.K == 5 ? 28 : c.K == 7 ? 76 : 56)) {
+    a.w16 = c.w16;
+    a.nslab = c.nslab16;
+    a.rows_major = 0;
+    int cfg, rows_t, cols_t;
+    if (c.mtiles16 % 4 == 0) {
+      const long long tiles_a = (long long)((n_max + 127) / 128) * (c.mtiles16 / 4) * B;
+      cfg = tiles_a >= 256 ? BF_A : BF_B;
+      rows_t = 128;
+      cols_t = cfg == BF_A ? 128 : 64;
+    } else {
+      cfg = BF_C;
+      rows_t = 64;
+      cols_t = 128;
+    }
+    out->a = a;
+    out->K = c.K;
+    out->MB = 1;
+    out->shape = cfg;
+    out->epi = epi;
+    out->cls = cls;
+    out->bf16 = 3;
+    out->grid = dim3((n_max + cols_t - 1) / cols_t, (c.mtiles16 * 32) / rows_t, B);
+    out->flop = 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B;
+    out->empty = false;
+    return 0;
+  }
   int MB = c.MB;
   int ytiles = c.mtiles / MB;
   // Tile shape: the largest tile that still yields >= min_tiles workgroups, otherwise the
@@ -181,6 +220,21 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   const int MB = p.MB, shape = p.shape;
   const dim3 grid = p.grid;
   int rc = 0;
+  if (p.bf16) {
+#define BF16_LAUNCH(KK)                                                                                                          \
+  if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a);      \
+  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
+    switch (p.K) {
+      case 3: BF16_LAUNCH(3); break;
+      case 5: BF16_LAUNCH(5); break;
+      case 7: BF16_LAUNCH(7); break;
+      case 11: BF16_LAUNCH(11); break;
+      default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d in bf16 mode", p.K);
+    }
+#undef BF16_LAUNCH
+    return rc;
+  }
   if (p.epi == EPI_LINEAR) {
     switch (p.K) {
       case 1: rc = launch_conv_k<1, EPI_LINEAR>(s, MB, shape, grid, a); break;
@@ -246,7 +300,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   const ConvPlan& p0 = plans[ord[0]];
   for (int i = 0; i < 3; ++i) {
     const ConvPlan& p = plans[ord[i]];
-    if (p.empty || p.epi != EPI_LINEAR || p.shape != p0.shape || p.MB != p0.MB || p.grid.z != p0.grid.z) return 1;
+    if (p.empty || p.epi != EPI_LINEAR || p.shape != p0.shape || p.MB != p0.MB || p.grid.z != p0.grid.z || p.bf16 != p0.bf16) return 1;
     if ((p.K - 1) * p.a.dil + ((4 - p.a.pad % 4) % 4) > (p.K == 3 ? 16 : p.K == 5 ? 28 : p.K == 7 ? 76 : p.K == 11 ? 56 : -1)) return 1;
     if (p.a.x_ld % 4) return 1;
   }
@@ -265,9 +319,27 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   g.off[3] = off_wg;
   const dim3 grid(off_wg, 1, p0.grid.z);
   const int k0 = plans[ord[0]].K, k1 = plans[ord[1]].K, k2 = plans[ord[2]].K;
+  const bool taps_ok = (k0 == 11 && k1 == 7 && k2 == 3) || (k0 == 7 && k1 == 5 && k2 == 3);
+  if (p0.bf16) {
+    if (!taps_ok) return 1;
+    ProfScope ps(ctx, w, p0.cls, flop, s);
+#define BF16_GROUP(KA, KB, KC)                                                                                                                     \
+  if (p0.shape == BF_A)                                                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+                       grid, dim3(256), 0, s, g);                                                                                                  \
+  else if (p0.shape == BF_B)                                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+                       grid, dim3(256), 0, s, g);                                                                                                  \
+  else                                                                                                                                             \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+                       grid, dim3(256), 0, s, g)
+    if (k0 == 11) { BF16_GROUP(11, 7, 3); }
+    else { BF16_GROUP(7, 5, 3); }
+#undef BF16_GROUP
+    return 0;
+  }
   const bool shape_ok = (p0.shape == TILE_TINY) || (p0.shape == TILE_SMALL && p0.MB == 2) || (p0.shape == TILE_W128 && p0.MB == 1) ||
                         (p0.shape == TILE_NB2 && p0.MB == 2);
-  const bool taps_ok = (k0 == 11 && k1 == 7 && k2 == 3) || (k0 == 7 && k1 == 5 && k2 == 3);
   if (!shape_ok || !taps_ok) return 1;
   ProfScope ps(ctx, w, p0.cls, flop, s);
   if (k0 == 11) return launch_group_k<11, 7, 3>(s, p0.MB, p0.shape, grid, g);
@@ -283,11 +355,12 @@ struct PairPlan {
   bool ok = false;  // geometry covered by the fused kernel
 };
 static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs, int ld, const int* len,
-                      int len_mul, int dil, float alpha, int accum, int B, int Lmax, int host_len, PairPlan* out) {
+                      int len_mul, int dil, float alpha, int accum, int B, int Lmax, int host_len, PairPlan* out, int precision = 0) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_PAIR_FUSION"); return e && std::atoi(e) != 0; }();
   const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
   out->ok = false;
+  if (precision == MI355TTS_PRECISION_BF16X3 && c1.w16 && c2.w16) return;  // split-bf16 mode runs these convs un-fused on the bf16 cores
   if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
       (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y || Lmax <= 0)
     return;

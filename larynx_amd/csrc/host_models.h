@@ -31,6 +31,10 @@ struct DevConv {
   const float* bias = nullptr;
   int mtiles = 0, noct = 0, K = 0, rows = 0, Cin = 0, Cout = 0, MB = 1;
   bool has_bias = false;
+  // split-bf16 copy of the weights (conv_bf16.h), present for the convs that mode covers
+  size_t w16_off = 0;  // offset (uint16 elements) into the model's bf16 arena
+  const void* w16 = nullptr;
+  int mtiles16 = 0, nslab16 = 0;
 };
 
 struct ArenaBuilder {
@@ -150,6 +154,8 @@ struct HifiResConv {
 struct HifiModel {
   mi355tts_hifigan_hparams hp;
   float* arena = nullptr;
+  uint16_t* arena16 = nullptr;  // split-bf16 weight fragments of the ResBlock convs
+  std::atomic<int> precision{0};  // 0 = exact f32 MFMA, 1 = split-bf16 (3 x bf16 MFMA) for the wide ResBlock convs
   DevConv pre, post;
   std::vector<DevConv> ups;
   // [stage][kernel][dilation index]

@@ -25,6 +25,7 @@
 #include "../../include/mi355tts.h"
 #include "conv_mfma.h"
 #include "resblock_pair.h"
+#include "conv_bf16.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -78,6 +79,7 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
     if (kv.second->arena) hipFree(kv.second->arena);
   for (auto& kv : ctx->hifi) {
     if (kv.second->arena) hipFree(kv.second->arena);
+    if (kv.second->arena16) hipFree(kv.second->arena16);
     if (kv.second->bias_spec) hipFree(kv.second->bias_spec);
   }
   delete ctx;
@@ -348,6 +350,16 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   auto hm = std::make_unique<HifiModel>();
   hm->hp = h;
   ArenaBuilder ab;
+  std::vector<uint16_t> ab16;  // split-bf16 fragments (conv_bf16.h) of the ResBlock convs with >= 64 channels
+  auto add16 = [&](DevConv& d, const float* w, int ch, int k) {
+    if (ch < 64 || (ch % 32)) return;
+    PackedConv16 p = pack_conv_bf16(ch, ch >= 128 ? 4 : 2, ch, k, [&](int co, int ci, int kk) { return w[((size_t)co * ch + ci) * k + kk]; });
+    d.w16_off = (ab16.size() + 127) & ~(size_t)127;  // 256-byte alignment
+    ab16.resize(d.w16_off + p.w.size());
+    std::memcpy(ab16.data() + d.w16_off, p.w.data(), p.w.size() * sizeof(uint16_t));
+    d.mtiles16 = p.mtiles;
+    d.nslab16 = p.nslab;
+  };
   const int C0 = h.upsample_initial_channel;
 #define TAKE(var, name, n)                         \
   const float* var = bl.take((name).c_str(), (n)); \
@@ -383,10 +395,13 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
           TAKE(b2, rb + ".convs2." + std::to_string(d) + ".bias", ch);
           rc.c1 = add_conv(ab, w1, b1, ch, ch, k, ROWS_PLAIN);
           rc.c2 = add_conv(ab, w2, b2, ch, ch, k, ROWS_PLAIN);
+          add16(rc.c1, w1, ch, k);
+          add16(rc.c2, w2, ch, k);
         } else {
           TAKE(w1, rb + ".convs." + std::to_string(d) + ".weight", (int64_t)ch * ch * k);
           TAKE(b1, rb + ".convs." + std::to_string(d) + ".bias", ch);
           rc.c1 = add_conv(ab, w1, b1, ch, ch, k, ROWS_PLAIN);
+          add16(rc.c1, w1, ch, k);
         }
         hm->rb[i][j].push_back(rc);
       }
@@ -399,6 +414,12 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   }
 #undef TAKE
   CHECK(upload_arena(ctx, ab, &hm->arena));
+  if (!ab16.empty()) {
+    hipError_t e = hipMalloc(&hm->arena16, ab16.size() * sizeof(uint16_t) + 256);
+    if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc bf16 weight arena: %s", hipGetErrorString(e));
+    HIPCHECK(hipMemcpy(hm->arena16, ab16.data(), ab16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
+  auto fix16 = [&](DevConv& c) { c.w16 = c.mtiles16 ? (const void*)(hm->arena16 + c.w16_off) : nullptr; };
   const float* A = hm->arena;
   fix(hm->pre, A);
   fix(hm->post, A);
@@ -407,7 +428,11 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     for (auto& kk : st)
       for (auto& rc : kk) {
         fix(rc.c1, A);
-        if (h.resblock_type == 1) fix(rc.c2, A);
+        fix16(rc.c1);
+        if (h.resblock_type == 1) {
+          fix(rc.c2, A);
+          fix16(rc.c2);
+        }
       }
   std::lock_guard<std::mutex> lk(ctx->mu);
   const int id = ctx->next_id++;
@@ -430,10 +455,26 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
   auto v = ctx->hifi.find(model);
   if (v != ctx->hifi.end()) {
     hipFree(v->second->arena);
+    if (v->second->arena16) hipFree(v->second->arena16);
     if (v->second->bias_spec) hipFree(v->second->bias_spec);
     ctx->hifi.erase(v);
     return 0;
   }
+  return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
+}
+
+extern "C" int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision) {
+  if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
+  if (precision != MI355TTS_PRECISION_F32 && precision != MI355TTS_PRECISION_BF16X3)
+    return fail(MI355TTS_ERR_INVALID, "unknown precision %d", precision);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto v = ctx->hifi.find(model);
+  if (v != ctx->hifi.end()) {
+    v->second->precision.store(precision);
+    return 0;
+  }
+  // GlowTTS (4 % of the path's FLOPs) always computes in exact f32: the switch is accepted and has no effect
+  if (ctx->glow.find(model) != ctx->glow.end()) return 0;
   return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
 }
 

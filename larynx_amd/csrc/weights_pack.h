@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 namespace mi355tts {
@@ -50,6 +51,57 @@ inline PackedConv pack_conv(int vrows, int m_align_tiles, int Cin, int K, RowMap
       }
     }
   }
+  return p;
+}
+
+// ---- split-bf16 fragments for conv_bf16.h -------------------------------------------------------
+inline uint16_t bf16_rne(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+struct PackedConv16 {
+  std::vector<uint16_t> w;  // [mtiles][nslab][K][plane hi/lo][64 lanes][8]
+  int mtiles = 0, nslab = 0, K = 0;
+};
+
+// lane l of (m-tile, 16-channel slab, tap) holds weights of row 32*mt + (l & 31), channels
+// 16*slab + 8*(l >> 5) .. +7 — the A operand of one v_mfma_f32_32x32x16_bf16 — once as bf16(w)
+// ("hi") and once as bf16(w - hi) ("lo").  Rows padded to whole `m_align` tiles, channels to whole
+// 32-channel chunks (two slabs), with zeros.
+template <typename WGet>
+inline PackedConv16 pack_conv_bf16(int rows, int m_align, int Cin, int K, WGet wget) {
+  PackedConv16 p;
+  int mt = (rows + 31) / 32;
+  mt = ((mt + m_align - 1) / m_align) * m_align;
+  p.mtiles = mt;
+  p.nslab = 2 * ((Cin + 31) / 32);
+  p.K = K;
+  p.w.assign((size_t)mt * p.nslab * K * 2 * 64 * 8, 0);
+  for (int m = 0; m < mt; ++m)
+    for (int slab = 0; slab < p.nslab; ++slab)
+      for (int k = 0; k < K; ++k)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = m * 32 + (lane & 31);
+          if (co >= rows) continue;
+          uint16_t* hi = &p.w[(((((size_t)m * p.nslab + slab) * K + k) * 2 + 0) * 64 + lane) * 8];
+          uint16_t* lo = hi + 64 * 8;
+          for (int i = 0; i < 8; ++i) {
+            const int ci = slab * 16 + 8 * (lane >> 5) + i;
+            const float v = ci < Cin ? wget(co, ci, k) : 0.f;
+            hi[i] = bf16_rne(v);
+            lo[i] = bf16_rne(v - bf16_to_float(hi[i]));
+          }
+        }
   return p;
 }
 

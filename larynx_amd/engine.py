@@ -126,6 +126,11 @@ class Engine:
             ffi.check(self.lib, fn(self._ctx, C.byref(hp_c), blob.ctypes.data, total, 0, C.byref(model)))
         return int(model.value)
 
+    def set_precision(self, model: int, precision: int):
+        """`ffi.PRECISION_F32` (exact, default) or `ffi.PRECISION_BF16X3` (split-bf16 ResBlock convs:
+        the reference's `half` switch)."""
+        ffi.check(self.lib, self.lib.mi355tts_model_set_precision(self._ctx, int(model), int(precision)))
+
     def unload(self, model: int):
         ffi.check(self.lib, self.lib.mi355tts_unload(self._ctx, model))
 

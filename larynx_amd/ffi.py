@@ -22,6 +22,8 @@ DEFAULT_LIBRARY = PACKAGE_DIR / "libmi355tts.so"
 MAX_STAGES = 8
 IN_DEVICE = 1
 OUT_DEVICE = 2
+PRECISION_F32 = 0
+PRECISION_BF16X3 = 1
 
 
 class GlowHParamsC(C.Structure):
@@ -84,6 +86,7 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
     "mi355tts_load_glow": (C.c_int, [_VP, C.POINTER(GlowHParamsC), _VP, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "mi355tts_load_hifigan": (C.c_int, [_VP, C.POINTER(HifiGanHParamsC), _VP, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "mi355tts_unload": (C.c_int, [_VP, C.c_int]),
+    "mi355tts_model_set_precision": (C.c_int, [_VP, C.c_int, C.c_int]),
     "mi355tts_glow_infer": (
         C.c_int,
         [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,

@@ -9,6 +9,7 @@ from concurrent.futures import Executor
 import numpy as np
 
 from .constants import ARRAY_OR_TENSOR, InferenceBackend, SettingsType, VocoderModel, VocoderModelConfig
+from . import ffi
 from .engine import MelBatch
 from .hparams import HifiGanHParams
 from .runtime import find_checkpoint, get_engine, read_config
@@ -33,8 +34,6 @@ class HipHiFiGanVocoder(VocoderModel):
         super().__init__(config)
         if config.backend not in (None, InferenceBackend.HIP):
             raise ValueError(f"Unknown backend: {config.backend}")
-        if config.half:
-            raise ValueError("the HIP backend computes in fp32 (parity mode); half=True is not supported")
         self.engine = get_engine(device, library_path)
         cfg = model_config if model_config is not None else read_config(config.model_path)
         self.hparams = HifiGanHParams.from_config(cfg)
@@ -44,6 +43,11 @@ class HipHiFiGanVocoder(VocoderModel):
             _LOGGER.debug("Loading HiFi-GAN checkpoint from %s", ckpt)
             state_dict = load_state_dict(ckpt, "generator")
         self.model_id = self.engine.load_hifigan(self.hparams, state_dict)
+        # `half` (larynx/hifi_gan.py:96-97 calls `.half()` on the generator): the wide ResBlock convs move to the
+        # bf16 matrix cores with split operands (3 x bf16 MFMA per product, f32 accumulate) — see conv_bf16.h
+        self.half = bool(config.half)
+        if self.half:
+            self.engine.set_precision(self.model_id, ffi.PRECISION_BF16X3)
         self.denoiser_strength = float(config.denoiser_strength)
 
     def mels_to_audio(self, mels: ARRAY_OR_TENSOR, settings: typing.Optional[SettingsType] = None) -> np.ndarray:

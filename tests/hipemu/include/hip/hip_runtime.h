@@ -54,6 +54,7 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
@@ -100,6 +101,8 @@ struct WaveState {
   float B[2 * 32];
   float A16[16 * 4];
   float B16[4 * 16];
+  float Ab[32 * 16];
+  float Bb[16 * 32];
 };
 
 struct BlockCtx {
@@ -187,6 +190,31 @@ inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l supplies 8 consecutive k of A row l&31 and of B column l&31,
+// k = 8*(l>>5) .. +7; D as for the 32x32 f32 MFMA.  Products of bf16 values are exact in f32;
+// accumulated here in k order (the hardware's internal order is not specified — tests allow for it).
+typedef __bf16 bf16x8_emu __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_f32_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
+  BlockCtx* cx = ctx();
+  Fiber* f = cx->cur;
+  WaveState& w = cx->waves[f->wave];
+  const int l = f->lane;
+  for (int i = 0; i < 8; ++i) {
+    w.Ab[(l & 31) * 16 + 8 * (l >> 5) + i] = (float)a[i];
+    w.Bb[(8 * (l >> 5) + i) * 32 + (l & 31)] = (float)b[i];
+  }
+  wave_barrier();
+  const int col = l & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) acc = std::fmaf(w.Ab[row * 16 + k], w.Bb[k * 32 + col], acc);
+    c[reg] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur()->tid)
@@ -217,6 +245,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_f32_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_f32_16x16x4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)

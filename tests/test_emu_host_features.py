@@ -229,3 +229,50 @@ def test_grouped_mrf_launches_resblock2(emu_engine):
     hp = HP.HifiGanHParams(resblock="2", upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=64,
                            resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)), num_mels=16)
     check_grouped_schedule(emu_engine, hp, 73, [19])
+
+
+def check_bf16x3_mode(eng, hp, seed, frames, rms_tol):
+    """`half`-style reduced precision: the wide ResBlock convs on the bf16 matrix cores with split
+    operands (three bf16 MFMAs per product, f32 accumulate).  Close to — not equal to — the exact
+    mode, within the documented tolerance of the oracle; switching back restores the exact bits."""
+    sd = synthetic.make_hifigan_state_dict(hp, seed=seed)
+    v = eng.load_hifigan(hp, sd)
+    rng = np.random.default_rng(seed + 1)
+    fr = np.asarray(frames, np.int32)
+    melin = (rng.standard_normal((len(fr), hp.num_mels, int(fr.max()))) * 2).astype(np.float32)
+    mb = eng.mel_from_numpy(melin, fr)
+    exact, _ = eng.hifigan_infer(v, mb)
+    eng.set_precision(v, ffi.PRECISION_BF16X3)
+    try:
+        split, _ = eng.hifigan_infer(v, mb)
+        eng.set_option("mrf_group", 0)
+        split_ungrouped, _ = eng.hifigan_infer(v, mb)
+    finally:
+        eng.set_option("mrf_group", 1)
+        eng.set_precision(v, ffi.PRECISION_F32)
+    again, _ = eng.hifigan_infer(v, mb)
+    assert np.array_equal(exact, again) and np.array_equal(split, split_ungrouped)
+    assert not np.array_equal(exact, split)  # the mode really ran
+    errs = []
+    for b in range(len(fr)):
+        ref = hifi_gan_np.hifigan_infer(sd, hp, melin[b, :, : fr[b]])
+        n = fr[b] * hp.hop
+        errs.append(float(np.sqrt(np.mean((split[b, :n] - ref) ** 2))))
+        assert errs[-1] < rms_tol, errs
+        assert np.all(split[b, n:] == 0)
+    with pytest.raises(ffi.Mi355ttsError):
+        eng.set_precision(v, 7)
+    eng.unload(v)
+    return max(errs)
+
+
+def test_bf16x3_mode_resblock1(emu_engine):
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    check_bf16x3_mode(emu_engine, hp, 81, [23, 9], 1e-4)
+
+
+def test_bf16x3_mode_resblock2_and_256_channels(emu_engine):
+    hp = HP.HifiGanHParams(resblock="2", upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=512,
+                           resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)), num_mels=16)
+    check_bf16x3_mode(emu_engine, hp, 83, [11], 1e-4)

@@ -369,3 +369,31 @@ def test_shortest_utterances_full_size_models(gpu_engine, n_ids):
     wav, _ = gpu_engine.hifigan_infer(v, mel)
     refw = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_MEDIUM, audio_np.mel_to_vocoder_input(ref, s))
     assert np.sqrt(np.mean((wav[0] - refw) ** 2)) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["ljspeech_high_echo", "ljspeech_high_S120", "ljspeech_medium_dave_ls12", "ljspeech_low_echo"])
+def test_bf16x3_mode_against_the_reference(gpu_engine, name):
+    """The reference's `half` switch on this backend = split-bf16 ResBlock convs (conv_bf16.h).  Documented
+    tolerance vs the reference's f32 output: waveform RMS <= 1e-4 (north_star's f32 bar still holds — the
+    split keeps 16 mantissa bits per operand and accumulates in f32), int16 within 8 LSB; the exact mode is
+    untouched by switching back and forth."""
+    from larynx_amd import ffi
+
+    c = load_case(name)
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    exact, _ = gpu_engine.hifigan_infer(v, mb)
+    gpu_engine.set_precision(v, ffi.PRECISION_BF16X3)
+    try:
+        wav, i16 = gpu_engine.hifigan_infer(v, mb)
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+    again, _ = gpu_engine.hifigan_infer(v, mb)
+    assert np.array_equal(exact, again)
+    rms = float(np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)))
+    mx = float(np.abs(wav[0] - c["wav"]).max())
+    d16 = int(np.abs(i16[0].astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
+    print(f"bf16x3 {name}: rms {rms:.3e} max {mx:.3e} int16 {d16} LSB")
+    if c["voc_hp"].upsample_initial_channel >= 128:
+        assert not np.array_equal(exact, wav)  # the mode ran (stages with >= 64 channels exist)
+    assert rms <= WAV_RMS_TOL and d16 <= 8, (rms, mx, d16)
