@@ -137,11 +137,11 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty, int r
 }
 
 // LDS floats one workgroup of a tile shape needs (staging double buffer, reused by the k-group reduction)
-template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 constexpr int conv_lds_floats() {
   constexpr bool SCATTER = (EPI == EPI_LINEAR || EPI == EPI_GATE);
   constexpr int NBR = (SCATTER && NB > 2) ? 1 : NB;
-  constexpr int RED = (KS - 1) * WN * NBR * 16 * 64;
+  constexpr int RED = (KS - 1) * WM * WN * NBR * 16 * 64;
   constexpr int XS = 2 * CI_C * (WN * NB * 32 + HALO);
   return XS > RED ? XS : RED;
 }
@@ -149,15 +149,19 @@ constexpr int conv_lds_floats() {
 // One workgroup's tile of the implicit GEMM: rows [32*MB*tile_y, +32*MB) x columns [T_T*tile_x, +T_T) of
 // batch row b.  `xs` = conv_lds_floats<...>() floats of LDS.  Called by conv_mfma_kernel (one conv per
 // launch) and by conv_group_kernel (the same-shaped convs of the three MRF chains in ONE launch).
-template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
+  // WM > 1 (EPI_LINEAR only): WM row groups of waves share ONE staged input tile — a workgroup then covers
+  // WM*MB*32 output rows, so the input is staged once per WM m-tiles instead of once per m-tile.
+  static_assert(WM == 1 || EPI == EPI_LINEAR, "row groups of waves are implemented for the linear epilogue");
   // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
   // (NB blocks of 32 columns each); the KS k-groups split the staged input
   // channels between them (octet o goes to group o % KS) and are summed through
   // LDS before the epilogue: two (or four) waves per SIMD from ONE staged tile,
   // which is what hides the LDS/L2 latencies at batch 1 where there are fewer
   // tiles than SIMDs.
-  constexpr int NWAVES = WN * KS;
+  constexpr int NWAVES = WM * WN * KS;
+  constexpr int WX = WM * WN;  // waves per k-group
   constexpr int NT = 64 * NWAVES;
   constexpr int T_T = WN * NB * 32;  // time columns per workgroup
   constexpr int XW = T_T + HALO;     // LDS row stride (floats)
@@ -168,17 +172,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
   // (LINEAR / GATE) may go NBR column blocks per round to bound it
   constexpr bool SCATTER = (EPI == EPI_LINEAR || EPI == EPI_GATE);
   constexpr int NBR = (SCATTER && NB > 2) ? 1 : NB;
-  constexpr int RED = (KS - 1) * WN * NBR * 16 * 64;
-  constexpr int LDSF = conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI>();
+  constexpr int RED = (KS - 1) * WX * NBR * 16 * 64;
+  constexpr int LDSF = conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>();
   static_assert(CI_C % 8 == 0 && CI_C % NWAVES == 0 && OCTS % KS == 0, "bad tile parameters");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave % WN;
-  const int kg = wave / WN;
+  const int wm = wave % WM;
+  const int wn = (wave / WM) % WN;
+  const int kg = wave / WX;
+  const int wx = wm * WN + wn;  // this wave's slot inside its k-group
   const int t0 = tile_x * T_T;
-  const int mt0 = tile_y * MB;
+  const int mt0 = (tile_y * WM + wm) * MB;
 
   const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
   const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
@@ -467,7 +473,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
               for (int nbi = 0; nbi < NBR; ++nbi)
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
-                  red[((((g * (KS - 1) + si) * WN + wn) * NBR + nbi) * R + rr) * 64 + lane] = acc[mb][nb0 + nbi][reg_of(g, rr)];
+                  red[((((g * (KS - 1) + si) * WX + wx) * NBR + nbi) * R + rr) * 64 + lane] = acc[mb][nb0 + nbi][reg_of(g, rr)];
             }
           __syncthreads();
 #pragma unroll
@@ -476,7 +482,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
             for (int nbi = 0; nbi < NBR; ++nbi)
 #pragma unroll
               for (int rr = 0; rr < R; ++rr)
-                own[mb][nb0 + nbi][rr] += red[((((kg * (KS - 1) + si) * WN + wn) * NBR + nbi) * R + rr) * 64 + lane];
+                own[mb][nb0 + nbi][rr] += red[((((kg * (KS - 1) + si) * WX + wx) * NBR + nbi) * R + rr) * 64 + lane];
         }
     }
   } else if constexpr (KS > 1) {
@@ -491,7 +497,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            red[((((kg - 1) * WN + wn) * NB + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+            red[((((kg - 1) * WX + wx) * NB + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
       }
       __syncthreads();
       if (kg == 0) {
@@ -501,7 +507,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              acc[mb][nb][r] += red[((((g - 1) * WN + wn) * NB + nb) * 16 + r) * 64 + lane];
+              acc[mb][nb][r] += red[((((g - 1) * WX + wx) * NB + nb) * 16 + r) * 64 + lane];
       }
     }
     if (kg > 0) return;
@@ -763,13 +769,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
 }
 
 
-template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
+template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 // (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
-__global__ __launch_bounds__(64 * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
-  __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI>()];
+__global__ __launch_bounds__(64 * WM * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
+  __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>()];
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
-  conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI>(a, tile_x, tile_y, blockIdx.z, xs);
+  conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // The MRF chains of a HiFi-GAN stage (hifi_gan/models.py:191-197) run convs of the SAME geometry
@@ -786,11 +792,11 @@ struct ConvGroupArgs {
   int gx[3], gy[3];  // tile grid of each member (x = time tiles, y = row tiles)
   int off[4];        // first workgroup of each member (multiples of 8), off[3] = grid size
 };
-template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2>
-__global__ __launch_bounds__(64 * WN * KS, (NB == 1 && MB == 2) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {
-  constexpr int L0 = conv_lds_floats<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR>();
-  constexpr int L1 = conv_lds_floats<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR>();
-  constexpr int L2 = conv_lds_floats<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR>();
+template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2, int WM = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, (NB == 1 && MB == 2) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {
+  constexpr int L0 = conv_lds_floats<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR, WM>();
+  constexpr int L1 = conv_lds_floats<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR, WM>();
+  constexpr int L2 = conv_lds_floats<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR, WM>();
   __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
@@ -798,17 +804,17 @@ __global__ __launch_bounds__(64 * WN * KS, (NB == 1 && MB == 2) ? 4 : 1) void co
   if (lin < g.off[1]) {
     if (lin >= g.gx[0] * g.gy[0]) return;
     xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
-    conv_tile<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR>(g.c[0], tx, ty, b, xs);
+    conv_tile<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR, WM>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
     if (l >= g.gx[1] * g.gy[1]) return;
     xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
-    conv_tile<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR>(g.c[1], tx, ty, b, xs);
+    conv_tile<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR, WM>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
     if (l >= g.gx[2] * g.gy[2]) return;
     xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
-    conv_tile<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR>(g.c[2], tx, ty, b, xs);
+    conv_tile<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR, WM>(g.c[2], tx, ty, b, xs);
   }
 }
 

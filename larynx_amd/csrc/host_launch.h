@@ -57,7 +57,10 @@ template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 //           weight bytes per MFMA of a 64-row tile and 4 k-groups; measured 7-14 % faster than the
 //           4 x 2-wave 64-row tile it replaced, and equal or better than SMALL at the same tile count
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3 };
+//   M128  : 4 row groups x 2 time-waves, no k-split: 128 rows x 128 columns from ONE staged input tile (the 32-row
+//           shapes stage the same input once per m-tile: 4x at 128 channels) and no k-group reduction; ResBlock convs
+//           whose rows are whole 128-row groups and that still yield >= 256 such tiles
+enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3, TILE_M128 = 4 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -69,6 +72,13 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   if ((K - 1) * a.dil + ((4 - a.pad % 4) % 4) > HALO)
     return fail(MI355TTS_ERR_INVALID, "conv K=%d dilation=%d exceeds the staged halo", K, a.dil);
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
+  if constexpr (EPI == EPI_LINEAR && K >= 3) {
+    if (shape == TILE_M128) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 32, 1, 2, 2, 1, HALO, EPI, 4>), grid, dim3(512), 0, s, a);
+      return 0;
+    }
+  }
+  if (shape == TILE_M128) return fail(MI355TTS_ERR_INVALID, "internal: the 128-row tile is a ResBlock conv shape");
   if (MB == 1) {
     if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
@@ -84,6 +94,12 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
     return 0;
   }
   return fail(MI355TTS_ERR_INVALID, "paired epilogues run on 32-row tiles (MB == 1)");
+}
+
+// workgroups a launch must yield before the 128-row tile is used (tests lower it to reach the shape at small sizes)
+static long long m128_min_tiles() {
+  const char* e = std::getenv("MI355TTS_M128_MIN_TILES");
+  return e ? std::atoll(e) : 256;
 }
 
 // A conv launch, decided but not yet issued: arguments, tile shape and grid.
@@ -170,6 +186,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   if (tiles(256) >= want) shape = TILE_NB2;
   else if (tiles(128) >= want) shape = TILE_W128;
   else if (tiles(64) >= want) shape = TILE_SMALL;
+  bool pinned = false;
   {  // tuning / test knob: MI355TTS_FORCE_TILE=0|1|2 pins the tile shape
     static const int forced = [] {
       const char* e = std::getenv("MI355TTS_FORCE_TILE");
@@ -178,7 +195,10 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     int f = forced;
     if (const char* dyn = std::getenv("MI355TTS_FORCE_TILE_DYNAMIC")) f = std::atoi(dyn);
     if (g_pin_tile >= 0) f = g_pin_tile;
-    if (f >= TILE_SMALL && f <= TILE_LAST) shape = f;
+    if (f >= TILE_SMALL && f <= TILE_LAST) {
+      shape = f;
+      pinned = true;
+    }
   }
   // a launch that cannot even give every CU one workgroup: halve the row tile too
   // (32-row m-tiles are independent in the packed weights; paired epilogues need both)
@@ -189,6 +209,15 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   if (shape == TILE_W128 && MB == 2) {
     MB = 1;
     ytiles = rows32;
+  }
+  {
+    static const bool no_m128 = [] { const char* e = std::getenv("MI355TTS_NO_M128"); return e && std::atoi(e) != 0; }();
+    if (!no_m128 && !pinned && epi == EPI_LINEAR && cls == KC_RESBLOCK && c.K >= 3 && rows32 % 4 == 0 && c.rows == rows32 * 32 &&
+        (long long)((n_max + 127) / 128) * (rows32 / 4) * B >= m128_min_tiles()) {
+      shape = TILE_M128;
+      MB = 1;
+      ytiles = rows32 / 4;
+    }
   }
   const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   // Which operand the 8 XCD L2s replicate: dealing TIME tiles across the XCDs makes every L2 fetch all the
@@ -285,6 +314,9 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   else if (shape == TILE_SMALL && MB == 2) launch_group_inst<K0, K1, K2, 32, 2, 1, 2, 4>(s, grid, g);
   else if (shape == TILE_W128 && MB == 1) launch_group_inst<K0, K1, K2, 32, 1, 2, 2, 4>(s, grid, g);
   else if (shape == TILE_NB2 && MB == 2) launch_group_inst<K0, K1, K2, 16, 2, 2, 4, 2>(s, grid, g);
+  else if (shape == TILE_M128)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 32, 1, 2, 2, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
+                       grid, dim3(512), 0, s, g);
   else return 1;
   return 0;
 }
@@ -339,7 +371,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     return 0;
   }
   const bool shape_ok = (p0.shape == TILE_TINY) || (p0.shape == TILE_SMALL && p0.MB == 2) || (p0.shape == TILE_W128 && p0.MB == 1) ||
-                        (p0.shape == TILE_NB2 && p0.MB == 2);
+                        (p0.shape == TILE_NB2 && p0.MB == 2) || p0.shape == TILE_M128;
   if (!shape_ok || !taps_ok) return 1;
   ProfScope ps(ctx, w, p0.cls, flop, s);
   if (k0 == 11) return launch_group_k<11, 7, 3>(s, p0.MB, p0.shape, grid, g);

@@ -276,3 +276,24 @@ def test_bf16x3_mode_resblock2_and_256_channels(emu_engine):
     hp = HP.HifiGanHParams(resblock="2", upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=512,
                            resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)), num_mels=16)
     check_bf16x3_mode(emu_engine, hp, 83, [11], 1e-4)
+
+
+def test_128_row_tile_shape(emu_engine, monkeypatch):
+    """TILE_M128 (four row groups of waves share one staged input tile, no k-split) is chosen for ResBlock convs with
+    >= 256 such tiles — here forced at emulator sizes; also inside the grouped launch and against the one-conv form."""
+    monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    check_grouped_schedule(emu_engine, hp, 91, [70, 33])
+    x = np.random.default_rng(3).standard_normal((2, 128, 300)).astype(np.float32)
+    w = (np.random.default_rng(4).standard_normal((128, 128, 7)) / 30).astype(np.float32)
+    bias = np.random.default_rng(5).standard_normal(128).astype(np.float32)
+    lens = np.array([300, 201], np.int32)
+    y = emu_engine.conv1d(x, w, bias, dilation=3, in_slope=0.1, lens=lens)  # KC_RESBLOCK class op: takes the M128 shape
+    from oracle import nn_np
+
+    for b in range(2):
+        n = lens[b]
+        ref = nn_np.conv1d(nn_np.leaky_relu(x[b, :, :n], 0.1), w, bias, dilation=3, padding=9)
+        np.testing.assert_allclose(y[b, :, :n], ref, rtol=1e-4, atol=5e-5)
+        assert np.all(y[b, :, n:] == 0)
