@@ -60,9 +60,7 @@ template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 //   M128  : 4 row groups x 2 time-waves, no k-split: 128 rows x 128 columns from ONE staged input tile (the 32-row
 //           shapes stage the same input once per m-tile: 4x at 128 channels) and no k-group reduction; ResBlock convs
 //           whose rows are whole 128-row groups and that still yield >= 256 such tiles
-//   M128S : the same with 64 columns (one time-wave, two column blocks) and the staged channels split over 2 k-groups:
-//           128-row launches with too few 128-column tiles (stage 0 of 'high' at batch 1: 256 channels x 4992 columns)
-enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3, TILE_M128 = 4, TILE_M128S = 5 };
+enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3, TILE_M128 = 4 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
 template <int K, int EPI>
@@ -80,13 +78,7 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
       return 0;
     }
   }
-  if constexpr (EPI == EPI_LINEAR && K >= 3) {
-    if (shape == TILE_M128S) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 32, 1, 2, 1, 2, HALO, EPI, 4>), grid, dim3(512), 0, s, a);
-      return 0;
-    }
-  }
-  if (shape == TILE_M128 || shape == TILE_M128S) return fail(MI355TTS_ERR_INVALID, "internal: the 128-row tile is a ResBlock conv shape");
+  if (shape == TILE_M128) return fail(MI355TTS_ERR_INVALID, "internal: the 128-row tile is a ResBlock conv shape");
   if (MB == 1) {
     if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
@@ -225,17 +217,9 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
       shape = TILE_M128;
       MB = 1;
       ytiles = rows32 / 4;
-    } else if (!no_m128 && !pinned && epi == EPI_LINEAR && cls == KC_RESBLOCK && c.K >= 3 && rows32 % 4 == 0 && c.rows == rows32 * 32 &&
-               (long long)((n_max + 63) / 64) * (rows32 / 4) * B >= m128_min_tiles() / 2) {
-      static const bool no_s = [] { const char* e = std::getenv("MI355TTS_NO_M128S"); return e && std::atoi(e) != 0; }();
-      if (!no_s) {
-        shape = TILE_M128S;
-        MB = 1;
-        ytiles = rows32 / 4;
-      }
     }
   }
-  const int T_T = shape == TILE_TINY ? 32 : (shape == TILE_SMALL || shape == TILE_M128S) ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
   // Which operand the 8 XCD L2s replicate: dealing TIME tiles across the XCDs makes every L2 fetch all the
   // weights (8 W + X bytes from memory, and W must fit 4 MB or it is re-streamed per time tile); dealing ROW
   // tiles makes every L2 fetch the whole input and 1/8 of the weights (W + 8 X).  Rows when the weights are
@@ -333,9 +317,6 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   else if (shape == TILE_M128)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 32, 1, 2, 2, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
                        grid, dim3(512), 0, s, g);
-  else if (shape == TILE_M128S)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 32, 1, 2, 1, 2, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
-                       grid, dim3(512), 0, s, g);
   else return 1;
   return 0;
 }
@@ -390,7 +371,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     return 0;
   }
   const bool shape_ok = (p0.shape == TILE_TINY) || (p0.shape == TILE_SMALL && p0.MB == 2) || (p0.shape == TILE_W128 && p0.MB == 1) ||
-                        (p0.shape == TILE_NB2 && p0.MB == 2) || p0.shape == TILE_M128 || p0.shape == TILE_M128S;
+                        (p0.shape == TILE_NB2 && p0.MB == 2) || p0.shape == TILE_M128;
   if (!shape_ok || !taps_ok) return 1;
   ProfScope ps(ctx, w, p0.cls, flop, s);
   if (k0 == 11) return launch_group_k<11, 7, 3>(s, p0.MB, p0.shape, grid, g);

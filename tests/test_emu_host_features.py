@@ -278,12 +278,10 @@ def test_bf16x3_mode_resblock2_and_256_channels(emu_engine):
     check_bf16x3_mode(emu_engine, hp, 83, [11], 1e-4)
 
 
-@pytest.mark.parametrize("min_tiles", ["1", "8"])
-def test_128_row_tile_shape(emu_engine, monkeypatch, min_tiles):
+def test_128_row_tile_shape(emu_engine, monkeypatch):
     """TILE_M128 (four row groups of waves share one staged input tile, no k-split) is chosen for ResBlock convs with
-    >= 256 such tiles, TILE_M128S (64 columns, 2 k-groups) below that — here forced at emulator sizes ("8" lands the
-    [2 x 128 x 300] op and the grouped vocoder launches on M128S); inside the grouped launch and as single convs."""
-    monkeypatch.setenv("MI355TTS_M128_MIN_TILES", min_tiles)
+    >= 256 such tiles — here forced at emulator sizes; also inside the grouped launch and against the one-conv form."""
+    monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
     check_grouped_schedule(emu_engine, hp, 91, [70, 33])
