@@ -156,6 +156,7 @@ def main():
                          "reports the median.  0 = as many as fit ~2 s, at least 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true")
+    ap.add_argument("--no-half-mode", action="store_true", help="skip the secondary bf16x3 (`half` switch) leg")
     ap.add_argument("--config3-utterances", type=int, default=256)
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the headline pass with the MRF chains on one stream too (for rocprofv3 kernel traces)")
@@ -342,7 +343,7 @@ def main():
     # ---- the reference's `half` switch on this backend: split-bf16 ResBlock convs (secondary figure; the
     # headline above is the exact f32 mode).  Same steps, same method, fewer repeats.
     half = None
-    if args.precision == "f32" and not args.tiny:
+    if args.precision == "f32" and not args.tiny and not args.no_half_mode:
         eng.set_precision(v, ffi.PRECISION_BF16X3)
         run_steps(0, max(W, conc))
         step(W)

@@ -107,8 +107,7 @@ int mi355tts_unload(mi355tts_ctx* ctx, int model);
 /* The reference's `half` switch (TextToSpeechModelConfig.half / VocoderModelConfig.half,
  * larynx/constants.py:58,85; `.half()` at larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97).
  * MI355TTS_PRECISION_F32 (default): exact f32 MFMA everywhere — the parity mode.
- * MI355TTS_PRECISION_BF16X3: the HiFi-GAN ResBlock convs with >= 64 channels (93 % of the path's
- * FLOPs) run on the bf16 matrix cores with split operands (x = hi + lo, three bf16 MFMAs per
+ * MI355TTS_PRECISION_BF16X3: the HiFi-GAN ResBlock convs (93 % of the path's FLOPs) run on the bf16 matrix cores with split operands (x = hi + lo, three bf16 MFMAs per
  * product, f32 accumulate): ~1e-5 relative error per layer instead of exact f32.  GlowTTS models
  * accept the call and keep computing in f32. */
 #define MI355TTS_PRECISION_F32 0

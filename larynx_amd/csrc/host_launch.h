@@ -117,6 +117,7 @@ enum Bf16Cfg {
   BF_A = 0,  // 4 x 1 waves, NB = 4: 128 rows x 128 columns
   BF_B = 1,  // 4 x 1 waves, NB = 2: 128 rows x  64 columns (few-tile launches)
   BF_C = 2,  // 2 x 2 waves, NB = 2:  64 rows x 128 columns (64-channel stages)
+  BF_D = 3,  // 1 x 4 waves, NB = 2:  32 rows x 256 columns (32-channel stages)
 };
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
@@ -157,10 +158,14 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
       cfg = tiles_a >= 256 ? BF_A : BF_B;
       rows_t = 128;
       cols_t = cfg == BF_A ? 128 : 64;
-    } else {
+    } else if (c.mtiles16 == 2) {
       cfg = BF_C;
       rows_t = 64;
       cols_t = 128;
+    } else {
+      cfg = BF_D;
+      rows_t = 32;
+      cols_t = 256;
     }
     out->a = a;
     out->K = c.K;
@@ -253,7 +258,8 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
 #define BF16_LAUNCH(KK)                                                                                                          \
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a);      \
   else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
+  else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 1, 4, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
     switch (p.K) {
       case 3: BF16_LAUNCH(3); break;
       case 5: BF16_LAUNCH(5); break;
@@ -362,8 +368,11 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   else if (p0.shape == BF_B)                                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
-  else                                                                                                                                             \
+  else if (p0.shape == BF_C)                                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+                       grid, dim3(256), 0, s, g);                                                                                                  \
+  else                                                                                                                                             \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
                        grid, dim3(256), 0, s, g)
     if (k0 == 11) { BF16_GROUP(11, 7, 3); }
     else { BF16_GROUP(7, 5, 3); }

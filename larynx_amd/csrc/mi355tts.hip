@@ -350,10 +350,10 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   auto hm = std::make_unique<HifiModel>();
   hm->hp = h;
   ArenaBuilder ab;
-  std::vector<uint16_t> ab16;  // split-bf16 fragments (conv_bf16.h) of the ResBlock convs with >= 64 channels
+  std::vector<uint16_t> ab16;  // split-bf16 fragments (conv_bf16.h) of the ResBlock convs
   auto add16 = [&](DevConv& d, const float* w, int ch, int k) {
-    if (ch < 64 || (ch % 32)) return;
-    PackedConv16 p = pack_conv_bf16(ch, ch >= 128 ? 4 : 2, ch, k, [&](int co, int ci, int kk) { return w[((size_t)co * ch + ci) * k + kk]; });
+    if (ch < 32 || (ch % 32)) return;
+    PackedConv16 p = pack_conv_bf16(ch, ch >= 128 ? 4 : ch / 32, ch, k, [&](int co, int ci, int kk) { return w[((size_t)co * ch + ci) * k + kk]; });
     d.w16_off = (ab16.size() + 127) & ~(size_t)127;  // 256-byte alignment
     ab16.resize(d.w16_off + p.w.size());
     std::memcpy(ab16.data() + d.w16_off, p.w.data(), p.w.size() * sizeof(uint16_t));

@@ -297,3 +297,9 @@ def test_128_row_tile_shape(emu_engine, monkeypatch):
         ref = nn_np.conv1d(nn_np.leaky_relu(x[b, :, :n], 0.1), w, bias, dilation=3, padding=9)
         np.testing.assert_allclose(y[b, :, :n], ref, rtol=1e-4, atol=5e-5)
         assert np.all(y[b, :, n:] == 0)
+
+
+def test_bf16x3_mode_64_and_32_channel_stages(emu_engine):
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    check_bf16x3_mode(emu_engine, hp, 85, [150, 37], 1e-4)

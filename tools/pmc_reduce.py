@@ -9,8 +9,7 @@ rows = csv.DictReader(open(sys.argv[1]))
 agg = collections.OrderedDict()
 for r in rows:
     name = r["Kernel_Name"]
-    m = re.search(r"conv_mfma_kernel<([^>]*)>", name)
-    short = f"conv_mfma_kernel<{m.group(1)}>" if m else re.sub(r"\(.*", "", name).replace("void ", "").replace("mi355tts::", "")
+    short = re.sub(r"\(.*", "", name).replace("void ", "").replace("mi355tts::", "")
     key = (short, r["Counter_Name"])
     a = agg.setdefault(key, [0, 0.0])
     a[0] += 1

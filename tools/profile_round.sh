@@ -4,11 +4,11 @@
 #   WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes), MFMA-busy PMC pass.
 # Usage: tools/profile_round.sh r01
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches --concurrency 1"
+BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-half-mode --concurrency 1 --repeats 1"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH > $OUT/bench_write.log 2>&1

@@ -7,7 +7,7 @@ import shutil
 import sys
 from pathlib import Path
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC = Path("gpurun_out") / R
 DST = Path("profiles")
 DST.mkdir(exist_ok=True)
@@ -30,8 +30,7 @@ stats = {r["Name"]: r for r in csv.DictReader(open(DST / f"{R}_kernel_stats.csv"
 def short(n):
     import re
 
-    m = re.search(r"conv_mfma_kernel<([^>]*)>", n)
-    return f"conv_mfma_kernel<{m.group(1)}>" if m else re.sub(r"\(.*", "", n).replace("void ", "").replace("mi355tts::", "")
+    return re.sub(r"\(.*", "", n).replace("void ", "").replace("mi355tts::", "")
 
 
 rows = []
@@ -51,7 +50,9 @@ for full, st in stats.items():
                      fetch_kb=(f[1] / f[0]) if f else None, write_kb=(w[1] / w[0]) if w else None, mfma_util=util))
 rows.sort(key=lambda r: -r["pct"])
 with open(DST / f"{R}_summary.md", "w") as out:
-    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial-branches --concurrency 1`\n\n")
+    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-half-mode --concurrency 1 --repeats 1`\n\n"
+              "(the product schedule of a call that has the GPU to itself: one stream, the three MRF chains' same-geometry convs / fused pairs as ONE "
+              "grouped launch — `conv_group_kernel` for the 256/128-channel stages, `pair_group_kernel` for the 64/32-channel stages)\n\n")
     out.write("Sources: `--kernel-trace --stats` (durations), separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and SQ passes "
               "(tools/profile_round.sh).  FETCH/WRITE are KB per dispatch as rocprofv3 reports them; on gfx950 FETCH_SIZE "
               "under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md §HBM) — the conv kernel reads its "
@@ -66,19 +67,16 @@ with open(DST / f"{R}_summary.md", "w") as out:
 # dominant kernel class = the HiFi-GAN ResBlock launches: LINEAR conv instances with K in {3,7,11}
 # (wide stages) plus the fused conv-pair kernel (32/64-channel stages)
 def is_dom(k):
-    if k.startswith("resblock_pair_kernel"):
-        return True
-    return k.startswith("conv_mfma_kernel<") and k.split("<")[1].split(",")[0] in ("3", "7", "11") and k.rstrip(">").endswith(" 0")
+    return k.startswith("pair_group_kernel") or k.startswith("conv_group_kernel") or k.startswith("resblock_pair_kernel")
 
 
 dom = [r for r in rows if is_dom(r["kernel"])]
 n = sum(r["calls"] for r in dom)
 traffic = sum(r["calls"] * ((r["fetch_kb"] or 0) + (r["write_kb"] or 0)) for r in dom) * 1024.0 / n
 avg_us = sum(r["calls"] * r["avg_us"] for r in dom) / n
-json.dump({"round": R, "kernel_class": "HiFi-GAN ResBlock launches: conv_mfma_kernel LINEAR K in {3,7,11} + resblock_pair_kernel",
+json.dump({"round": R, "kernel_class": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (64/32-channel stages)",
            "dispatches": n, "avg_us": avg_us, "hbm_bytes_per_launch_raw": traffic,
-           "note": "FETCH_SIZE+WRITE_SIZE (KB x 1024) per dispatch, separate PMC passes, no gfx950 x2 read correction applied; "
-                   "the class also contains the GlowTTS encoder's few k=3 convs"},
+           "note": "FETCH_SIZE+WRITE_SIZE (KB x 1024) per dispatch, separate PMC passes, no gfx950 x2 read correction applied"},
           open(DST / f"{R}_roofline_traffic.json", "w"), indent=1)
 print(open(DST / f"{R}_summary.md").read())
 print(open(DST / f"{R}_roofline_traffic.json").read())
