@@ -771,7 +771,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
 
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 // (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
-__global__ __launch_bounds__(64 * WM * WN * KS, (EPI == EPI_LINEAR && NB == 1 && MB == 2) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && NB == 1 && MB == 2) || WM == 4) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
   __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>()];
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
@@ -793,7 +793,8 @@ struct ConvGroupArgs {
   int off[4];        // first workgroup of each member (multiples of 8), off[3] = grid size
 };
 template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2, int WM = 1>
-__global__ __launch_bounds__(64 * WM * WN * KS, (NB == 1 && MB == 2) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {
+// (second launch bound = waves per SIMD: 4 keeps every member under 128 VGPRs, i.e. two 8-wave workgroups per CU)
+__global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4 || (MB == 1 && NB == 2 && KS == 4)) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {
   constexpr int L0 = conv_lds_floats<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR, WM>();
   constexpr int L1 = conv_lds_floats<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR, WM>();
   constexpr int L2 = conv_lds_floats<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR, WM>();

@@ -74,7 +74,7 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
   if constexpr (EPI == EPI_LINEAR && K >= 3) {
     if (shape == TILE_M128) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 32, 1, 2, 2, 1, HALO, EPI, 4>), grid, dim3(512), 0, s, a);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 2, 1, HALO, EPI, 4>), grid, dim3(512), 0, s, a);
       return 0;
     }
   }
@@ -117,7 +117,7 @@ enum Bf16Cfg {
   BF_A = 0,  // 4 x 1 waves, NB = 4: 128 rows x 128 columns
   BF_B = 1,  // 4 x 1 waves, NB = 2: 128 rows x  64 columns (few-tile launches)
   BF_C = 2,  // 2 x 2 waves, NB = 2:  64 rows x 128 columns (64-channel stages)
-  BF_D = 3,  // 1 x 4 waves, NB = 2:  32 rows x 256 columns (32-channel stages)
+  BF_D = 3,  // 1 x 4 waves, NB = 1:  32 rows x 128 columns (32-channel stages; 256 columns would need 85 KB of LDS)
 };
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
@@ -165,7 +165,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     } else {
       cfg = BF_D;
       rows_t = 32;
-      cols_t = 256;
+      cols_t = 128;
     }
     out->a = a;
     out->K = c.K;
@@ -259,7 +259,7 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a);      \
   else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
   else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 1, 4, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 1, 4, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
     switch (p.K) {
       case 3: BF16_LAUNCH(3); break;
       case 5: BF16_LAUNCH(5); break;
@@ -320,8 +320,8 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   else if (shape == TILE_SMALL && MB == 2) launch_group_inst<K0, K1, K2, 32, 2, 1, 2, 4>(s, grid, g);
   else if (shape == TILE_W128 && MB == 1) launch_group_inst<K0, K1, K2, 32, 1, 2, 2, 4>(s, grid, g);
   else if (shape == TILE_NB2 && MB == 2) launch_group_inst<K0, K1, K2, 16, 2, 2, 4, 2>(s, grid, g);
-  else if (shape == TILE_M128)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 32, 1, 2, 2, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
+  else if (shape == TILE_M128)  // 16-channel chunks: 121 VGPRs, two 8-wave workgroups per CU (32-channel chunks need 169 and spill under the cap)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 16, 1, 2, 2, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
                        grid, dim3(512), 0, s, g);
   else return 1;
   return 0;
@@ -372,7 +372,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else                                                                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 1, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
                        grid, dim3(256), 0, s, g)
     if (k0 == 11) { BF16_GROUP(11, 7, 3); }
     else { BF16_GROUP(7, 5, 3); }
