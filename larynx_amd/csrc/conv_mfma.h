@@ -771,7 +771,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
 
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 // (one-column-block variants sit at 110-135 VGPRs: ask for <= 128 so two workgroups share a CU)
-__global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && NB == 1 && MB == 2) || WM == 4) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && ((NB == 1 && MB == 2) || (MB == 1 && NB == 2 && KS == 4))) || WM == 4) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
   __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>()];
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
