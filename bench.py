@@ -496,7 +496,7 @@ def main():
                 "utterances_per_sec": world * K * B / dt_dn,
             },
             "half_mode": None if not half else {
-                "dtype": "bf16x3: the HiFi-GAN ResBlock convs with >= 64 channels on the bf16 matrix cores with split operands "
+                "dtype": "bf16x3: the HiFi-GAN ResBlock convs on the bf16 matrix cores with split operands "
                          "(x = hi + lo, three bf16 MFMAs per product, f32 accumulate; conv_bf16.h); everything else f32",
                 "what": "the reference's `half` switch (larynx/hifi_gan.py:96-97) on this backend; NOT the headline — reported next to it",
                 "parity": "waveform RMS 1.4e-6 vs the reference's f32 output on the golden set, int16 within 1 LSB "

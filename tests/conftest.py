@@ -21,6 +21,17 @@ def pytest_collection_modifyitems(config, items):
     """Tests marked `gpu` need a real MI355X: without one they are skipped, not failed
     (plain `pytest tests` on a CPU-only box then equals `-m "not gpu"`)."""
     if _gpu_present():
+        # torch wheels carry their own HIP runtime: in a process that uses both, torch's must come up before the
+        # library's first HIP call (INTEGRATION.md "Sharing a process with PyTorch") — some gpu tests hand torch
+        # tensors to the library, and any test may create the first engine
+        if any("gpu" in item.keywords for item in items):
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except ImportError:
+                pass
         return
     skip = pytest.mark.skip(reason="no AMD GPU visible (/dev/kfd): gpu-marked tests need a real MI355X")
     for item in items:
