@@ -188,3 +188,28 @@ def test_unsupported_requests_raise(emu_library, voice_dirs):
 
     with pytest.raises(Mi355ttsError):  # 4 frames x hop 8 = 32 samples: shorter than one STFT frame (the reference raises too)
         voc.mels_to_audio(np.zeros((1, HP.TINY_HIFIGAN.num_mels, 4), np.float32), {"denoiser_strength": 0.01})
+
+
+def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
+    """`half=True` (the reference's registry default for voices, larynx/__init__.py:297; `.half()` at
+    larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97): GlowTTS keeps computing in f32, the vocoder moves its
+    ResBlock convs to the split-bf16 kernels — same interface, audio within a few LSB of the exact mode."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    gdir, vdir = tmp_path / "half-glow_tts", tmp_path / "half_hifi_gan"
+    gdir.mkdir()
+    vdir.mkdir()
+    (gdir / "config.json").write_text(json.dumps(HP.TINY_GLOW.to_config()))
+    (vdir / "config.json").write_text(json.dumps(hp.to_config()))
+    np.savez(gdir / "generator.npz", **synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=3))
+    np.savez(vdir / "generator.npz", **synthetic.make_hifigan_state_dict(hp, seed=5))
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(9), 14, HP.TINY_GLOW.num_symbols)
+    out = {}
+    for half in (False, True):
+        tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, half=half, library_path=emu_library)
+        voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, half=half, library_path=emu_library)
+        assert voc.half is half
+        out[half] = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
+    assert out[True].shape == out[False].shape and out[True].dtype == np.int16
+    d = np.abs(out[True].astype(np.int32) - out[False].astype(np.int32))
+    assert d.max() <= 8 and not np.array_equal(out[True], out[False])

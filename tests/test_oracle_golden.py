@@ -90,3 +90,21 @@ def test_oracle_reproduces_config4_batch_rows():
         np.testing.assert_allclose(mel, c["mel"][b], atol=2e-5)
         wav = hifi_gan_np.hifigan_infer(vsd, c["voc_hp"], audio_np.mel_to_vocoder_input(c["mel"][b], s))
         assert np.sqrt(np.mean((wav - c["wav"][b]) ** 2)) < 5e-6
+
+
+def test_weight_norm_folding_matches_torch_to_float32_roundoff():
+    """`weights.fold_weight_norm` folds in float64 and rounds once; the reference's
+    `remove_weight_norm` is `torch._weight_norm(v, g, 0)` in float32.  On tensors of real-checkpoint shape and
+    magnitude the two agree to float32 round-off (a few ulp: torch accumulates the norm in float32), so the choice cannot
+    move parity."""
+    torch = pytest.importorskip("torch")
+    from larynx_amd.weights import fold_weight_norm
+
+    rng = np.random.default_rng(7)
+    for shape, scale in (((512, 80, 7), 0.02), ((256, 256, 11), 0.5), ((384, 192, 5), 3.0), ((192, 80, 1), 1e-3)):
+        v = (rng.standard_normal(shape) * scale).astype(np.float32)
+        g = np.abs(rng.standard_normal((shape[0], 1, 1)) * scale * 10 + 0.1).astype(np.float32)
+        ours = fold_weight_norm(g, v)
+        ref = torch._weight_norm(torch.from_numpy(v), torch.from_numpy(g), 0).numpy()
+        ulp = np.abs(ours - ref) / np.maximum(np.spacing(np.abs(ref)), 1e-45)
+        assert ulp.max() <= 4.0, (shape, float(ulp.max()))
