@@ -445,7 +445,8 @@ def main():
         if not tpath.is_file():
             tpath = REPO / "profiles" / "r01_roofline_traffic.json"
         if tpath.is_file():  # PMC counters cannot be read from inside this process: committed rocprofv3 passes
-            traffic = json.loads(tpath.read_text()).get("hbm_bytes_per_launch_raw")
+            tj = json.loads(tpath.read_text())
+            traffic = tj.get("hbm_bytes_per_launch", tj.get("hbm_bytes_per_launch_raw"))
         dom = prof["conv_mfma.hifigan_resblock"]
         dom_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         all_conv_ms = sum(v_["ms"] for k_, v_ in prof.items() if k_.startswith("conv_mfma"))
@@ -517,7 +518,10 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": dom_tf / FP32_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_source": f"profiles/{tpath.name if tpath.is_file() else '-'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                "traffic_source": f"profiles/{tpath.name if tpath.is_file() else '-'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
+                                  f"command, bytes per launch, FETCH_SIZE doubled per the guide's gfx950 correction for 16-B/lane reads)",
+                "algorithmic_bytes_per_launch": "in + out planes of the launch's three members: e.g. stage 1 of 'high' 3 x (20.4 + 20.4) MB = 123 MB; "
+                                                "class average 92 MB per launch (1656 MB per utterance over 18 launches)",
                 "algorithmic_flop_per_launch": dom["flop"] / max(1, dom["launches"]),
                 "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["ms"] / max(1, dom["launches"]),
