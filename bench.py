@@ -17,7 +17,9 @@ utterances are independent, so the timed region has no collective ("weak"
 scaling: every rank synthesises its own K utterances; max over ranks).  After
 the headline region every run also times BASELINE config 3 — 256 utterances,
 P ~ clip(N(120,15),60,200), LPT-sharded over the ranks, audio gathered to rank 0
-in sentence order — and reports it as `config3` (strong scaling).
+in sentence order — and reports it as `config3` (strong scaling), and BASELINE
+config 5 — 210 sentences cycling three resident voices, in-order delivery — as
+`config5` (time to first audio, sustained x real time).
 
 `--device cpu --library <emulator .so> --tiny` runs the same code path on the
 CPU emulator build with gloo (tests/test_bench_path.py, world size 2).
@@ -158,6 +160,11 @@ def main():
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-half-mode", action="store_true", help="skip the secondary bf16x3 (`half` switch) leg")
     ap.add_argument("--config3-utterances", type=int, default=256)
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--config5-sentences", type=int, default=210)
+    ap.add_argument("--config5-threads", type=int, default=3,
+                    help="host threads per GPU in the streaming config (the reference's raw-stream default is 2: fewer workers "
+                         "for latency to first audio, more for throughput)")
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the headline pass with the MRF chains on one stream too (for rocprofv3 kernel traces)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = the emulator build (tests only)")
@@ -436,6 +443,63 @@ def main():
                 "shard_sizes": [len(x) for x in sharding.lpt_assign(lengths, world)],
             }
 
+    # ---- BASELINE config 5: long multi-voice text as a stream — sentences cycling three resident voices (en V=46 /
+    # de V=54 / fr V=42), dealt round-robin to the ranks, each rank keeps `--config5-threads` batch-1 calls in flight
+    # and delivers its sentences in order (larynx/__main__.py:229-268 raw-stream semantics)
+    c5 = None
+    if not args.no_config5 and not args.tiny and on_gpu:
+        voices = [(ghp, g)]
+        for vhp2, seed2 in ((HP.THORSTEN, 2001), (HP.SIWIS, 2002)):
+            voices.append((vhp2, eng.load_glow(vhp2, synthetic.make_glow_state_dict(vhp2, seed=seed2))))  # seeded: identical on every rank
+        rng5 = np.random.default_rng(5)
+        sents = []
+        for i in range(args.config5_sentences):
+            hp_i, g_i = voices[i % 3]
+            sents.append((g_i, synthetic.synthetic_phoneme_ids(rng5, int(rng5.integers(40, 160)), hp_i.num_symbols)))
+        mine5 = list(range(rank, len(sents), world))
+        eng.reserve(args.config5_threads + 1, g, v, max_batch=1, max_ids=160, max_frames=160 * 12)
+
+        def sentence(i):
+            g_i, ids_i = sents[i]
+            fr, _, i16 = eng.synthesize(g_i, v, ids_i, 0.667, args.length_scale, seed=i, audio_settings=s,
+                                        frames_per_id_guess=12.0 / max(args.length_scale, 0.05))
+            return i16[0, : int(fr[0]) * hop]
+
+        with ThreadPoolExecutor(args.config5_threads) as pool5:
+            list(pool5.map(sentence, mine5[: 2 * args.config5_threads]))  # warm every worker / voice
+            barrier()
+            t0 = time.perf_counter()
+            futs = [pool5.submit(sentence, i) for i in mine5]
+            first, total5 = None, 0
+            for f in futs:  # in-order delivery
+                a5 = f.result()
+                if first is None:
+                    first = time.perf_counter() - t0
+                total5 += a5.shape[0]
+            barrier()
+            t5 = time.perf_counter() - t0
+        st5 = torch.tensor([t5, first, float(total5)], dtype=torch.float64, device=dev)
+        if world > 1:
+            mx5 = st5.clone()
+            dist.all_reduce(mx5, op=dist.ReduceOp.MAX)
+            sm5 = st5.clone()
+            dist.all_reduce(sm5, op=dist.ReduceOp.SUM)
+            st5 = torch.stack([mx5[0], mx5[1], sm5[2]])
+        if rank == 0:
+            c5 = {
+                "workload": f"{len(sents)} sentences of 40-160 ids cycling three resident GlowTTS voices (en-us V=46, de-de V=54, fr-fr V=42) "
+                            f"against one 'high' vocoder, dealt round-robin to {world} rank(s), {args.config5_threads} batch-1 calls in "
+                            f"flight per GPU, int16 to the host, delivered in sentence order per rank",
+                "sentences": len(sents),
+                "threads_per_gpu": args.config5_threads,
+                "seconds": float(st5[0]),
+                "ms_to_first_audio": 1e3 * float(st5[1]),
+                "sentences_per_sec": len(sents) / float(st5[0]),
+                "x_realtime": float(st5[2]) / SAMPLE_RATE / float(st5[0]),
+            }
+        for _, g_i in voices[1:]:
+            eng.unload(g_i)
+
     if rank == 0:
         audio_s = total_frames * hop / SAMPLE_RATE  # audio produced by all ranks in one K-step region
         utt_s = world * K * B / dt_flight
@@ -537,6 +601,8 @@ def main():
         }
         if c3 is not None:
             out["config3"] = c3
+        if c5 is not None:
+            out["config5"] = c5
         if not args.no_cpu_baseline and world == 1 and on_gpu and not args.tiny:
             out["cpu_baseline"] = cpu_baseline(ids_host[0], args.length_scale)  # = golden case ljspeech_high_S120
         print(json.dumps(out), flush=True)

@@ -50,7 +50,7 @@ for full, st in stats.items():
                      fetch_kb=(f[1] / f[0]) if f else None, write_kb=(w[1] / w[0]) if w else None, mfma_util=util))
 rows.sort(key=lambda r: -r["pct"])
 with open(DST / f"{R}_summary.md", "w") as out:
-    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-half-mode --concurrency 1 --repeats 1`\n\n"
+    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config5 --no-half-mode --concurrency 1 --repeats 1`\n\n"
               "(the product schedule of a call that has the GPU to itself: one stream, the three MRF chains' same-geometry convs / fused pairs as ONE "
               "grouped launch — `conv_group_kernel` for the 256/128-channel stages, `pair_group_kernel` for the 64/32-channel stages)\n\n")
     out.write("Sources: `--kernel-trace --stats` (durations), separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and SQ passes "
