@@ -248,10 +248,15 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     }
     mel = m;
   }
-  struct MelGuard {
+  struct MelGuard {  // error exits: nothing queued on the stream may still write the blocks that go back to the pool
     mi355tts_mel* m;
-    ~MelGuard() { mel_destroy(m); }
-  } mguard{mel};
+    hipStream_t st;
+    ~MelGuard() {
+      if (!m) return;
+      hipStreamSynchronize(st);
+      mel_destroy(m);
+    }
+  } mguard{mel, s};
   {
     ProfScope ps(ctx, w, KC_SMALL, 0);
     hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(64), 0, s, logw, (long long)P, d_len, length_scale, h.n_sqz, cum, P,
