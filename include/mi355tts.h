@@ -109,9 +109,13 @@ int mi355tts_unload(mi355tts_ctx* ctx, int model);
  * MI355TTS_PRECISION_F32 (default): exact f32 MFMA everywhere — the parity mode.
  * MI355TTS_PRECISION_BF16X3: the HiFi-GAN ResBlock convs (93 % of the path's FLOPs) run on the bf16 matrix cores with split operands (x = hi + lo, three bf16 MFMAs per
  * product, f32 accumulate): ~1e-5 relative error per layer instead of exact f32.  GlowTTS models
- * accept the call and keep computing in f32. */
+ * accept the call and keep computing in f32.
+ * MI355TTS_PRECISION_BF16: the same kernels with ONE bf16 MFMA per product (operands rounded to bf16, f32
+ * accumulate) — plain reduced precision like the reference's `.half()`: ~3e-3 relative per product, waveform
+ * RMS ~1e-3; no faster than the split mode on these shapes (both are bound by operand delivery). */
 #define MI355TTS_PRECISION_F32 0
 #define MI355TTS_PRECISION_BF16X3 1
+#define MI355TTS_PRECISION_BF16 2
 int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision);
 
 /* ---- GlowTTS: replaces GlowTextToSpeech.phonemes_to_mels --------------------

@@ -109,7 +109,7 @@ struct ConvPlan {
   dim3 grid;
   double flop = 0;
   bool empty = true;
-  int bf16 = 0;  // 0 = f32 kernel; 3 = split-bf16 kernel (conv_bf16.h), `shape` is then a Bf16Cfg
+  int bf16 = 0;  // 0 = f32 kernel; 3 = split-bf16 kernel, 1 = plain bf16 kernel (conv_bf16.h); `shape` is then a Bf16Cfg
 };
 
 // Tile configurations of the split-bf16 kernel (all 4 waves; a wave owns 1 x NB blocks over all input channels)
@@ -146,7 +146,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   a.noct = c.noct;
   a.Cin = c.Cin;
   a.rows = c.rows;
-  if (precision == MI355TTS_PRECISION_BF16X3 && c.w16 && epi == EPI_LINEAR && !a.x2 && !a.y2 && a.split >= c.rows && a.out_act == ACT_NONE &&
+  if ((precision == MI355TTS_PRECISION_BF16X3 || precision == MI355TTS_PRECISION_BF16) && c.w16 && epi == EPI_LINEAR && !a.x2 && !a.y2 && a.split >= c.rows && a.out_act == ACT_NONE &&
       (c.K == 3 || c.K == 5 || c.K == 7 || c.K == 11) && (a.x_ld % 4) == 0 &&
       (c.K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= (c.K == 3 ? 16 : c.K == 5 ? 28 : c.K == 7 ? 76 : 56)) {
     a.w16 = c.w16;
@@ -173,7 +173,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     out->shape = cfg;
     out->epi = epi;
     out->cls = cls;
-    out->bf16 = 3;
+    out->bf16 = precision == MI355TTS_PRECISION_BF16 ? 1 : 3;
     out->grid = dim3((n_max + cols_t - 1) / cols_t, (c.mtiles16 * 32) / rows_t, B);
     out->flop = 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B;
     out->empty = false;
@@ -255,11 +255,17 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   const dim3 grid = p.grid;
   int rc = 0;
   if (p.bf16) {
-#define BF16_LAUNCH(KK)                                                                                                          \
-  if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a);      \
-  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
-  else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a); \
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 1, 4, ConvCfg<KK>::HALO, 3>), grid, dim3(256), 0, s, a)
+#define BF16_LAUNCH_T(KK, TT)                                                                                                      \
+  if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a);      \
+  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
+  else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 1, 4, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a)
+#define BF16_LAUNCH(KK)            \
+  if (p.bf16 == 3) {               \
+    BF16_LAUNCH_T(KK, 3);          \
+  } else {                         \
+    BF16_LAUNCH_T(KK, 1);          \
+  }
     switch (p.K) {
       case 3: BF16_LAUNCH(3); break;
       case 5: BF16_LAUNCH(5); break;
@@ -267,6 +273,7 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
       case 11: BF16_LAUNCH(11); break;
       default: rc = fail(MI355TTS_ERR_INVALID, "unsupported conv kernel size %d in bf16 mode", p.K);
     }
+#undef BF16_LAUNCH_T
 #undef BF16_LAUNCH
     return rc;
   }
@@ -361,21 +368,28 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   if (p0.bf16) {
     if (!taps_ok) return 1;
     ProfScope ps(ctx, w, p0.cls, flop, s);
-#define BF16_GROUP(KA, KB, KC)                                                                                                                     \
+#define BF16_GROUP_T(KA, KB, KC, TT)                                                                                                                \
   if (p0.shape == BF_A)                                                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else if (p0.shape == BF_B)                                                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else if (p0.shape == BF_C)                                                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else                                                                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 1, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, 3>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 1, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g)
+#define BF16_GROUP(KA, KB, KC)      \
+  if (p0.bf16 == 3) {               \
+    BF16_GROUP_T(KA, KB, KC, 3);    \
+  } else {                          \
+    BF16_GROUP_T(KA, KB, KC, 1);    \
+  }
     if (k0 == 11) { BF16_GROUP(11, 7, 3); }
     else { BF16_GROUP(7, 5, 3); }
+#undef BF16_GROUP_T
 #undef BF16_GROUP
     return 0;
   }
@@ -401,7 +415,7 @@ static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, floa
   const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
   out->ok = false;
-  if (precision == MI355TTS_PRECISION_BF16X3 && c1.w16 && c2.w16) return;  // split-bf16 mode runs these convs un-fused on the bf16 cores
+  if (precision != MI355TTS_PRECISION_F32 && c1.w16 && c2.w16) return;  // the bf16 modes run these convs un-fused on the bf16 cores
   if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
       (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y || Lmax <= 0)
     return;

@@ -465,7 +465,7 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
 
 extern "C" int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
-  if (precision != MI355TTS_PRECISION_F32 && precision != MI355TTS_PRECISION_BF16X3)
+  if (precision != MI355TTS_PRECISION_F32 && precision != MI355TTS_PRECISION_BF16X3 && precision != MI355TTS_PRECISION_BF16)
     return fail(MI355TTS_ERR_INVALID, "unknown precision %d", precision);
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto v = ctx->hifi.find(model);

@@ -24,6 +24,7 @@ IN_DEVICE = 1
 OUT_DEVICE = 2
 PRECISION_F32 = 0
 PRECISION_BF16X3 = 1
+PRECISION_BF16 = 2
 
 
 class GlowHParamsC(C.Structure):

@@ -231,7 +231,7 @@ def test_grouped_mrf_launches_resblock2(emu_engine):
     check_grouped_schedule(emu_engine, hp, 73, [19])
 
 
-def check_bf16x3_mode(eng, hp, seed, frames, rms_tol):
+def check_bf16x3_mode(eng, hp, seed, frames, rms_tol, precision=ffi.PRECISION_BF16X3):
     """`half`-style reduced precision: the wide ResBlock convs on the bf16 matrix cores with split
     operands (three bf16 MFMAs per product, f32 accumulate).  Close to — not equal to — the exact
     mode, within the documented tolerance of the oracle; switching back restores the exact bits."""
@@ -242,7 +242,7 @@ def check_bf16x3_mode(eng, hp, seed, frames, rms_tol):
     melin = (rng.standard_normal((len(fr), hp.num_mels, int(fr.max()))) * 2).astype(np.float32)
     mb = eng.mel_from_numpy(melin, fr)
     exact, _ = eng.hifigan_infer(v, mb)
-    eng.set_precision(v, ffi.PRECISION_BF16X3)
+    eng.set_precision(v, precision)
     try:
         split, _ = eng.hifigan_infer(v, mb)
         eng.set_option("mrf_group", 0)
@@ -303,3 +303,14 @@ def test_bf16x3_mode_64_and_32_channel_stages(emu_engine):
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
     check_bf16x3_mode(emu_engine, hp, 85, [150, 37], 1e-4)
+
+
+def test_plain_bf16_mode(emu_engine):
+    """MI355TTS_PRECISION_BF16: one bf16 MFMA per product (operands rounded to 8 mantissa bits, f32 accumulate) —
+    the plain reduced precision of the reference's `.half()`; tolerance 2e-2 RMS on these O(0.2) waveforms, and
+    clearly coarser than the split mode."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
+    plain = check_bf16x3_mode(emu_engine, hp, 81, [23], 2e-2, precision=ffi.PRECISION_BF16)
+    split = check_bf16x3_mode(emu_engine, hp, 81, [23], 1e-4)
+    assert plain > 20 * split
