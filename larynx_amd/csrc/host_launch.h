@@ -57,9 +57,10 @@ template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 //           weight bytes per MFMA of a 64-row tile and 4 k-groups; measured 7-14 % faster than the
 //           4 x 2-wave 64-row tile it replaced, and equal or better than SMALL at the same tile count
 //   NB2   : 4 time-waves x 2 k-groups, 256 columns (64x64 outputs per wave)
-//   M128  : 4 row groups x 2 time-waves, no k-split: 128 rows x 128 columns from ONE staged input tile (the 32-row
+//   M128  : 4 row groups of waves (256 threads), no k-split: 128 rows x 64 columns from ONE staged input tile (the 32-row
 //           shapes stage the same input once per m-tile: 4x at 128 channels) and no k-group reduction; ResBlock convs
-//           whose rows are whole 128-row groups and that still yield >= 256 such tiles
+//           whose rows are whole 128-row groups and that yield >= 256 128-column tiles.  (Measured against the 8-wave
+//           128 x 128 form: +1.4 % on the class — finer granularity, four workgroups per CU.)
 enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3, TILE_M128 = 4 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
@@ -74,7 +75,7 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
   if constexpr (EPI == EPI_LINEAR && K >= 3) {
     if (shape == TILE_M128) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 2, 1, HALO, EPI, 4>), grid, dim3(512), 0, s, a);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 1, 1, HALO, EPI, 4>), grid, dim3(256), 0, s, a);
       return 0;
     }
   }
@@ -224,7 +225,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
       ytiles = rows32 / 4;
     }
   }
-  const int T_T = shape == TILE_TINY ? 32 : shape == TILE_SMALL ? 64 : (shape == TILE_NB2 ? 256 : 128);
+  const int T_T = shape == TILE_TINY ? 32 : (shape == TILE_SMALL || shape == TILE_M128) ? 64 : (shape == TILE_NB2 ? 256 : 128);
   // Which operand the 8 XCD L2s replicate: dealing TIME tiles across the XCDs makes every L2 fetch all the
   // weights (8 W + X bytes from memory, and W must fit 4 MB or it is re-streamed per time tile); dealing ROW
   // tiles makes every L2 fetch the whole input and 1/8 of the weights (W + 8 X).  Rows when the weights are
@@ -327,9 +328,9 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   else if (shape == TILE_SMALL && MB == 2) launch_group_inst<K0, K1, K2, 32, 2, 1, 2, 4>(s, grid, g);
   else if (shape == TILE_W128 && MB == 1) launch_group_inst<K0, K1, K2, 32, 1, 2, 2, 4>(s, grid, g);
   else if (shape == TILE_NB2 && MB == 2) launch_group_inst<K0, K1, K2, 16, 2, 2, 4, 2>(s, grid, g);
-  else if (shape == TILE_M128)  // 16-channel chunks: 121 VGPRs, two 8-wave workgroups per CU (32-channel chunks need 169 and spill under the cap)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 16, 1, 2, 2, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
-                       grid, dim3(512), 0, s, g);
+  else if (shape == TILE_M128)  // 16-channel chunks, one time-wave: <= 128 VGPRs, four 4-wave workgroups per CU
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 16, 1, 2, 1, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
+                       grid, dim3(256), 0, s, g);
   else return 1;
   return 0;
 }
