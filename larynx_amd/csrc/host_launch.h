@@ -116,7 +116,7 @@ struct ConvPlan {
 // Tile configurations of the split-bf16 kernel (all 4 waves; a wave owns 1 x NB blocks over all input channels)
 enum Bf16Cfg {
   BF_A = 0,  // 4 x 1 waves, NB = 4: 128 rows x 128 columns
-  BF_B = 1,  // 4 x 1 waves, NB = 2: 128 rows x  64 columns (few-tile launches)
+  BF_B = 1,  // 4 x 1 waves, NB = 1: 128 rows x  32 columns (few-tile launches: stage 0 of 'high' at batch 1; measured 2 % better than 64 columns)
   BF_C = 2,  // 2 x 2 waves, NB = 2:  64 rows x 128 columns (64-channel stages)
   BF_D = 3,  // 1 x 4 waves, NB = 1:  32 rows x 128 columns (32-channel stages; 256 columns would need 85 KB of LDS)
 };
@@ -158,7 +158,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
       const long long tiles_a = (long long)((n_max + 127) / 128) * (c.mtiles16 / 4) * B;
       cfg = tiles_a >= 256 ? BF_A : BF_B;
       rows_t = 128;
-      cols_t = cfg == BF_A ? 128 : 64;
+      cols_t = cfg == BF_A ? 128 : 32;
     } else if (c.mtiles16 == 2) {
       cfg = BF_C;
       rows_t = 64;
@@ -258,7 +258,7 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   if (p.bf16) {
 #define BF16_LAUNCH_T(KK, TT)                                                                                                      \
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a);      \
-  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
+  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
   else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 1, 4, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a)
 #define BF16_LAUNCH(KK)            \
@@ -374,7 +374,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else if (p0.shape == BF_B)                                                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 1, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
   else if (p0.shape == BF_C)                                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
