@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Soak test on one GPU: N host threads hammer one engine with random-length sentences on
-three resident voices and two vocoders, a share of the calls with the denoiser on; every
+three resident voices and three vocoders ('high' exact, 'low' exact, 'high' in the split-bf16 mode), a share of
+the calls through the fused one-call entry with pause padding, a share with the denoiser on; every
 result must be finite, of the expected length, identical when the whole job list is run a
 second time, and equal to a single-threaded recomputation for a sample.  VRAM use after
 pass 1 and pass 2 must match (leak check: workspaces are grow-only per worker).
@@ -38,19 +39,33 @@ def main():
     args = ap.parse_args()
     eng = Engine(0)
     s = ljspeech_audio_settings()
-    vocs = [(hp, eng.load_hifigan(hp, synthetic.make_hifigan_state_dict(hp, seed=1234))) for hp in (HP.HIFIGAN_HIGH, HP.HIFIGAN_LOW)]
+    from larynx_amd import ffi
+
+    vocs = [(hp, eng.load_hifigan(hp, synthetic.make_hifigan_state_dict(hp, seed=1234))) for hp in (HP.HIFIGAN_HIGH, HP.HIFIGAN_LOW, HP.HIFIGAN_HIGH)]
+    eng.set_precision(vocs[2][1], ffi.PRECISION_BF16X3)
     voices = [(hp, eng.load_glow(hp, synthetic.make_glow_state_dict(hp, seed=1234))) for hp in (HP.LJSPEECH, HP.THORSTEN, HP.SIWIS)]
     rng = np.random.default_rng(99)
     jobs = []
     for i in range(args.calls):
         ghp, g = voices[int(rng.integers(3))]
-        vhp, v = vocs[int(rng.integers(2))]
+        vhp, v = vocs[int(rng.integers(3))]
         B = 1 if rng.random() < 0.8 else int(rng.integers(2, 5))
         rows = [synthetic.synthetic_phoneme_ids(rng, int(rng.integers(1, 220)), ghp.num_symbols) for _ in range(B)]
-        jobs.append((i, g, v, vhp, rows, 0.01 if rng.random() < 0.2 else 0.0))
+        jobs.append((i, g, v, vhp, rows, 0.01 if rng.random() < 0.2 else 0.0, bool(rng.random() < 0.4)))
 
     def run(job):
-        i, g, v, vhp, rows, dn = job
+        i, g, v, vhp, rows, dn, fused = job
+        if fused:  # the one-call entry with SSML pause padding; frame counts come back with the audio
+            pb, pa = 37 * (i % 3), 11 * (i % 2)
+            frames, wav, i16 = eng.synthesize(g, v, rows if len(rows) > 1 else rows[0], 0.667, 0.8, seed=i, audio_settings=s,
+                                              pad_before=pb, pad_after=pa, want_float=True)
+            frames = [int(f) for f in frames]
+            assert np.isfinite(wav).all()
+            for b, f in enumerate(frames):
+                n = f * vhp.hop
+                assert np.all(i16[b, :pb] == 0) and np.all(i16[b, pb + n :] == 0)
+                assert n == 0 or np.abs(wav[b, pb : pb + n]).max() > 0
+            return i, frames, i16
         mel = eng.glow_infer(g, rows if len(rows) > 1 else rows[0], 0.667, 0.8, seed=i, audio_settings=s)
         frames = [int(f) for f in mel.frames]
         if dn > 0 and min(frames) * vhp.hop <= 1024:
