@@ -10,6 +10,7 @@ import typing
 
 import numpy as np
 
+from . import ffi
 from .audio import AudioSettings
 from .constants import ARRAY_OR_TENSOR, InferenceBackend, SettingsType, TextToSpeechModel, TextToSpeechModelConfig
 from .engine import MelBatch
@@ -51,7 +52,8 @@ class HipGlowTextToSpeech(TextToSpeechModel):
         if state_dict is None:
             ckpt = find_checkpoint(config.model_path)
             _LOGGER.debug("Loading GlowTTS checkpoint from %s", ckpt)
-            state_dict = load_state_dict(ckpt, "model")
+            names = [n for n, _ in ffi.manifest(self.engine.lib, ffi.glow_hparams_c(self.hparams))]
+            state_dict = load_state_dict(ckpt, "model", manifest_names=names, n_split=self.hparams.n_split)
         self.model_id = self.engine.load_glow(self.hparams, state_dict)
         self.noise_scale = 0.667
         self.length_scale = 1.0

@@ -41,7 +41,8 @@ class HipHiFiGanVocoder(VocoderModel):
         if state_dict is None:
             ckpt = find_checkpoint(config.model_path)
             _LOGGER.debug("Loading HiFi-GAN checkpoint from %s", ckpt)
-            state_dict = load_state_dict(ckpt, "generator")
+            names = [n for n, _ in ffi.manifest(self.engine.lib, ffi.hifigan_hparams_c(self.hparams))]
+            state_dict = load_state_dict(ckpt, "generator", manifest_names=names)
         self.model_id = self.engine.load_hifigan(self.hparams, state_dict)
         # `half` (larynx/hifi_gan.py:96-97 calls `.half()` on the generator): the wide ResBlock convs move to the
         # bf16 matrix cores with split operands (3 x bf16 MFMA per product, f32 accumulate) — see conv_bf16.h

@@ -23,16 +23,17 @@ def get_engine(device: int = 0, library_path=None) -> Engine:
 
 
 def find_checkpoint(model_path: Path) -> Path:
-    """`generator.pth` (the reference's torch checkpoint, `larynx/utils.py:203-209`
-    accepts it as a valid voice dir) or this project's `generator.npz`."""
-    for name in ("generator.npz", "generator.pth"):
+    """What `valid_voice_dir` (`larynx/utils.py:203-209`) accepts — `generator.pth` (the reference's torch
+    checkpoint) or `generator.onnx` (what released voices ship; its initializers are read, onnx_weights.py) —
+    or this project's `generator.npz`."""
+    for name in ("generator.npz", "generator.pth", "generator.onnx"):
         p = Path(model_path) / name
         if p.is_file():
             return p
-    raise FileNotFoundError(
-        f"{model_path}: no generator.pth / generator.npz (ONNX files cannot be ingested: "
-        "the HIP backend needs the checkpoint tensors)"
-    )
+    onnx = sorted(Path(model_path).glob("*.onnx")) if Path(model_path).is_dir() else []
+    if onnx:
+        return onnx[0]
+    raise FileNotFoundError(f"{model_path}: no generator.pth / generator.onnx / generator.npz")
 
 
 def read_config(model_path: Path) -> dict:

@@ -35,6 +35,8 @@ def fold_weight_norm(g: np.ndarray, v: np.ndarray) -> np.ndarray:
 def resolve_tensor(sd: StateDict, name: str) -> np.ndarray:
     """Look `name` (a manifest entry) up in a reference state-dict."""
     if name.endswith(".weight_inv"):
+        if name in sd:  # an ONNX export carries the stored inverse itself (onnx_weights.py)
+            return _np(sd[name]).astype(np.float32)
         # InvConvNear.store_inverse: torch.inverse(weight.float()) (layers.py:274-275)
         w = _np(sd[name[: -len("_inv")]]).astype(np.float32)
         return np.linalg.inv(w).astype(np.float32)
@@ -60,10 +62,18 @@ def build_blob(manifest: typing.Sequence[typing.Tuple[str, int]], sd: StateDict)
     return blob
 
 
-def load_state_dict(path: typing.Union[str, Path], key: str) -> StateDict:
+def load_state_dict(path: typing.Union[str, Path], key: str, manifest_names: typing.Optional[typing.Sequence[str]] = None,
+                    n_split: int = 4) -> StateDict:
     """Read a reference `generator.pth` (torch pickle, `{"model": sd}` for GlowTTS,
-    `{"generator": sd}` for HiFi-GAN) or this project's `.npz` of the same keys."""
+    `{"generator": sd}` for HiFi-GAN), this project's `.npz` of the same keys, or a released voice's
+    `generator.onnx` (its initializers, see onnx_weights.py; needs the library's manifest names)."""
     path = Path(path)
+    if path.suffix == ".onnx":
+        from .onnx_weights import state_dict_from_onnx
+
+        if manifest_names is None:
+            raise ValueError("reading an ONNX file needs the manifest's tensor names")
+        return state_dict_from_onnx(path, manifest_names, n_split=n_split)
     if path.suffix == ".npz":
         with np.load(path) as z:
             return {k: z[k] for k in z.files}
