@@ -268,3 +268,42 @@ def test_reference_sentence_task_with_mixed_models(ref_larynx, voices, emu_libra
     audio = larynx._sentence_task("t", ids, settings, AsArray(), {"noise_scale": 0.0}, voc, None, pause_before_ms=0, pause_after_ms=20)
     want = _oracle_audio(gsd, vsd, ids, 0, 20)
     assert audio.shape == want.shape and np.abs(audio.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_reference_registry_accepts_an_onnx_only_voice(ref_larynx, emu_library_path, monkeypatch, tmp_path):
+    """A released voice = `config.json` + `phonemes.txt` + `generator.onnx`: the reference's own `valid_voice_dir`
+    (larynx/utils.py:203-209) accepts it, its registry hands the directory to the HIP classes, and they read the
+    ONNX initializers (larynx_amd/onnx_weights.py).  Audio = the oracle on the checkpoint the export started from."""
+    import shutil
+
+    larynx = ref_larynx
+    fix = Path(__file__).resolve().parent / "golden" / "onnx"
+    gdir = tmp_path / "en-us" / "ljspeech-glow_tts"
+    vdir = tmp_path / "hifi_gan" / "universal_large"
+    gdir.mkdir(parents=True)
+    vdir.mkdir(parents=True)
+    cfg = json.loads((fix / "glow" / "config.json").read_text())
+    cfg["audio"].update({k: v for k, v in vars(ljspeech_audio_settings()).items() if k in (
+        "filter_length", "hop_length", "win_length", "sample_rate", "mel_fmin", "mel_fmax", "ref_level_db", "spec_gain",
+        "signal_norm", "min_level_db", "max_norm", "clip_norm", "symmetric_norm", "do_dynamic_range_compression",
+        "convert_db_to_amp")})
+    (gdir / "config.json").write_text(json.dumps(cfg))
+    (gdir / "phonemes.txt").write_text("".join(f"{i} p{i}\n" for i in range(GLOW.num_symbols)))
+    shutil.copy(fix / "glow" / "generator.onnx", gdir / "generator.onnx")
+    shutil.copy(fix / "hifigan" / "config.json", vdir / "config.json")
+    shutil.copy(fix / "hifigan" / "generator.onnx", vdir / "generator.onnx")
+    from larynx.utils import valid_voice_dir
+
+    assert valid_voice_dir(gdir) and valid_voice_dir(vdir)
+    _apply_integration_edits(monkeypatch, larynx, emu_library_path)
+    SENTENCES[:] = _fixture_sentences()[:1]
+    res = list(larynx.text_to_speech("x", voice_or_lang="ljspeech", vocoder_or_quality="high", backend="hip",
+                                     tts_settings={"noise_scale": 0.0}, custom_voices_dir=tmp_path))
+    with np.load(fix / "glow" / "state_dict.npz") as z:
+        gsd = {k: z[k] for k in z.files}
+    with np.load(fix / "hifigan" / "state_dict.npz") as z:
+        vsd = {k: z[k] for k in z.files}
+    sent = SENTENCES[0]
+    want = _oracle_audio(gsd, vsd, sent.words[0].phonemes, sent.pause_before_ms, sent.pause_after_ms)
+    assert len(res) == 1 and res[0].audio.shape == want.shape
+    assert np.abs(res[0].audio.astype(np.int32) - want.astype(np.int32)).max() <= 1
