@@ -153,7 +153,7 @@ template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, in
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
   // WM > 1 (EPI_LINEAR only): WM row groups of waves share ONE staged input tile — a workgroup then covers
   // WM*MB*32 output rows, so the input is staged once per WM m-tiles instead of once per m-tile.
-  static_assert(WM == 1 || EPI == EPI_LINEAR, "row groups of waves are implemented for the linear epilogue");
+  static_assert(WM == 1 || EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "row groups of waves: linear and upsample epilogues");
   // Workgroup = WN x KS waves.  The WN waves of a k-group tile the time axis
   // (NB blocks of 32 columns each); the KS k-groups split the staged input
   // channels between them (octet o goes to group o % KS) and are summed through

@@ -79,7 +79,13 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
       return 0;
     }
   }
-  if (shape == TILE_M128) return fail(MI355TTS_ERR_INVALID, "internal: the 128-row tile is a ResBlock conv shape");
+  if constexpr (EPI == EPI_UPSAMPLE) {
+    if (shape == TILE_M128) {  // the polyphase upsampler's virtual rows, 128 per workgroup from one staged input tile
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 1, 1, HALO, EPI, 4>), grid, dim3(256), 0, s, a);
+      return 0;
+    }
+  }
+  if (shape == TILE_M128) return fail(MI355TTS_ERR_INVALID, "internal: the 128-row tile is a ResBlock conv / upsampler shape");
   if (MB == 1) {
     if (shape == TILE_TINY) launch_conv_inst<K, 64, 1, 1, 1, 8, HALO, EPI>(s, grid, a);
     else if (shape == TILE_SMALL) launch_conv_inst<K, CI_SMALL, 1, 1, 2, 4, HALO, EPI>(s, grid, a);
@@ -218,7 +224,10 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   }
   {
     static const bool no_m128 = [] { const char* e = std::getenv("MI355TTS_NO_M128"); return e && std::atoi(e) != 0; }();
-    if (!no_m128 && !pinned && epi == EPI_LINEAR && cls == KC_RESBLOCK && c.K >= 3 && rows32 % 4 == 0 && c.rows == rows32 * 32 &&
+    static const bool no_m128u = [] { const char* e = std::getenv("MI355TTS_NO_M128_UPS"); return e && std::atoi(e) != 0; }();
+    const bool resblock_ok = epi == EPI_LINEAR && cls == KC_RESBLOCK && c.K >= 3;
+    const bool upsample_ok = epi == EPI_UPSAMPLE && !no_m128u && c.K >= 1 && c.K <= 3;  // 32 m-tiles re-stage the same input otherwise
+    if (!no_m128 && !pinned && (resblock_ok || upsample_ok) && rows32 % 4 == 0 && c.rows == rows32 * 32 &&
         (long long)((n_max + 127) / 128) * (rows32 / 4) * B >= m128_min_tiles()) {
       shape = TILE_M128;
       MB = 1;

@@ -314,3 +314,19 @@ def test_plain_bf16_mode(emu_engine):
     plain = check_bf16x3_mode(emu_engine, hp, 81, [23], 2e-2, precision=ffi.PRECISION_BF16)
     split = check_bf16x3_mode(emu_engine, hp, 81, [23], 1e-4)
     assert plain > 20 * split
+
+
+def test_128_row_tile_for_the_upsampler(emu_engine, monkeypatch):
+    """The polyphase ConvTranspose1d with whole 128-row groups of virtual rows (C_out * stride) also takes the 128-row
+    tile — the 32-row shapes stage the same input once per m-tile (32x at stage 1 of 'high')."""
+    from oracle import nn_np
+
+    monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
+    rng = np.random.default_rng(77)
+    for Cin, Cout, K, u, L in ((40, 16, 16, 8, 150), (24, 64, 4, 2, 301)):
+        x = rng.standard_normal((1, Cin, L)).astype(np.float32)
+        w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * 2)).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        y = emu_engine.conv_transpose1d(x, w, b, stride=u, in_slope=0.1)
+        ref = nn_np.conv_transpose1d(nn_np.leaky_relu(x[0], 0.1), w, b, stride=u, padding=(K - u) // 2)
+        np.testing.assert_allclose(y[0], ref, rtol=1e-4, atol=5e-5)
