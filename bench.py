@@ -198,20 +198,37 @@ def main():
         dev = torch.device("cuda", local)
     else:
         dev = torch.device("cpu")
-    if world > 1:
+    # under torch.distributed.run (the driver's launch form) the process group is always brought up — also at
+    # world size 1, so that the RCCL code path (init, broadcast, all_reduce, barrier, gather_object) is the one
+    # that runs whenever the script is launched that way
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if on_gpu:
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
+        # RCCL prints a version banner on fd 1 when its first communicator comes up; stdout carries the ONE JSON
+        # line of the contract, so fd 1 points at stderr until the group has done its first collective
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if on_gpu:
+                dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+            if on_gpu:
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     def sync():
         if on_gpu:
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sync()
 
@@ -232,7 +249,7 @@ def main():
         bv = build_blob(man_v, synthetic.make_hifigan_state_dict(vhp, seed=1234))
         blob.copy_(torch.from_numpy(np.concatenate([bg, bv])))
     t_b = time.perf_counter()
-    if world > 1:
+    if use_dist:
         dist.broadcast(blob, src=0)
     sync()
     broadcast_s = time.perf_counter() - t_b
@@ -370,7 +387,7 @@ def main():
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
                           half[0] if half else 0.0, half[1] if half else 0.0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -422,10 +439,10 @@ def main():
         barrier()
         t_job = time.perf_counter() - t0
         t0 = time.perf_counter()
-        merged = sharding.gather_in_order(local_out, len(rows)) if world > 1 else [local_out[i] for i in range(len(rows))]
+        merged = sharding.gather_in_order(local_out, len(rows)) if use_dist else [local_out[i] for i in range(len(rows))]
         t_gather = time.perf_counter() - t0
         tj = torch.tensor([t_job], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tj, op=dist.ReduceOp.MAX)
         if rank == 0:
             assert len(merged) == len(rows) and all(m.dtype == np.int16 and m.size > 0 for m in merged)
@@ -479,7 +496,7 @@ def main():
             barrier()
             t5 = time.perf_counter() - t0
         st5 = torch.tensor([t5, first, float(total5)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             mx5 = st5.clone()
             dist.all_reduce(mx5, op=dist.ReduceOp.MAX)
             sm5 = st5.clone()
@@ -573,7 +590,8 @@ def main():
                 "resblock_class_ms_per_step": half[2]["ms"] / K,
                 "resblock_class_f32_equivalent_tflops": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 if half[2]["ms"] > 0 else None,
             },
-            "weight_broadcast_seconds": broadcast_s if world > 1 else None,
+            "weight_broadcast_seconds": broadcast_s if use_dist else None,
+            "process_group": ("nccl (RCCL)" if on_gpu else "gloo") if use_dist else None,
             "roofline": {
                 "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (fused conv pairs, 64/32-channel stages)",
                 "bound": "mfma",
@@ -606,7 +624,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and on_gpu and not args.tiny:
             out["cpu_baseline"] = cpu_baseline(ids_host[0], args.length_scale)  # = golden case ljspeech_high_S120
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
