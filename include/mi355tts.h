@@ -104,6 +104,14 @@ int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams* hp, const
 int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_hparams* hp, const float* blob, int64_t numel,
                           int on_device, int* model_out);
 int mi355tts_unload(mi355tts_ctx* ctx, int model);
+/* Utterance-level data parallelism: the ONE collective of the path — rank `root`'s folded weight
+ * blob (device memory, `numel` floats: what mi355tts_load_*(on_device = 1) ingests) is broadcast over xGMI to the
+ * same-sized device buffer of every rank of the caller's RCCL communicator (`nccl_comm` is an ncclComm_t).  The
+ * library does not link RCCL: ncclBroadcast is resolved from the RCCL library already loaded in the caller's
+ * process (`rccl_library`: its path or soname, NULL = "librccl.so.1").  The reference is a single process and has
+ * no counterpart; a Python host broadcasts with torch.distributed instead (larynx_amd/sharding.py). */
+int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, int root, float* device_blob, int64_t numel,
+                               const char* rccl_library);
 /* The reference's `half` switch (TextToSpeechModelConfig.half / VocoderModelConfig.half,
  * larynx/constants.py:58,85; `.half()` at larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97).
  * MI355TTS_PRECISION_F32 (default): exact f32 MFMA everywhere — the parity mode.

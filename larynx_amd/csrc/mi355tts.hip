@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -461,6 +462,35 @@ extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
     return 0;
   }
   return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
+}
+
+// §8(e): the one collective of the path.  The library does not link RCCL: the entry point is resolved from the
+// RCCL library the CALLER's communicator belongs to (already loaded in its process).
+extern "C" int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, int root, float* device_blob, int64_t numel,
+                                          const char* rccl_library) {
+  if (!ctx || !nccl_comm || !device_blob || numel <= 0 || root < 0) return fail(MI355TTS_ERR_INVALID, "bad argument");
+  typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef const char* (*errstr_fn)(int);
+  const char* names[] = {rccl_library, "librccl.so.1", "librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    if (!n) continue;
+    lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // the instance that created the communicator
+    if (!lib && n == rccl_library) lib = dlopen(n, RTLD_NOW);
+    if (lib) break;
+  }
+  if (!lib) return fail(MI355TTS_ERR_INVALID, "RCCL library not loaded in this process (%s)", dlerror());
+  bcast_fn bcast = (bcast_fn)dlsym(lib, "ncclBroadcast");
+  errstr_fn errstr = (errstr_fn)dlsym(lib, "ncclGetErrorString");
+  if (!bcast) return fail(MI355TTS_ERR_INVALID, "ncclBroadcast not found in the RCCL library");
+  HIPCHECK(hipSetDevice(ctx->device));
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  const int rc = bcast(device_blob, device_blob, (size_t)numel, /*ncclFloat32*/ 7, root, nccl_comm, w->stream);
+  if (rc != 0) return fail(MI355TTS_ERR_HIP, "ncclBroadcast failed: %s", errstr ? errstr(rc) : "?");
+  HIPCHECK(hipStreamSynchronize(w->stream));
+  return 0;
 }
 
 extern "C" int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision) {

@@ -126,6 +126,13 @@ class Engine:
             ffi.check(self.lib, fn(self._ctx, C.byref(hp_c), blob.ctypes.data, total, 0, C.byref(model)))
         return int(model.value)
 
+    def broadcast_weights(self, nccl_comm: int, root: int, device_ptr: int, numel: int, rccl_library: typing.Optional[str] = None):
+        """`mi355tts_broadcast_weights`: ncclBroadcast of a device-resident weight blob over the caller's RCCL
+        communicator (an `ncclComm_t` as an integer), in place."""
+        lib_name = rccl_library.encode() if rccl_library else None
+        ffi.check(self.lib, self.lib.mi355tts_broadcast_weights(self._ctx, C.c_void_p(nccl_comm), int(root), C.c_void_p(device_ptr),
+                                                                int(numel), lib_name))
+
     def set_precision(self, model: int, precision: int):
         """`ffi.PRECISION_F32` (exact, default) or `ffi.PRECISION_BF16X3` (split-bf16 ResBlock convs:
         the reference's `half` switch)."""

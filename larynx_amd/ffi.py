@@ -88,6 +88,7 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
     "mi355tts_load_hifigan": (C.c_int, [_VP, C.POINTER(HifiGanHParamsC), _VP, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "mi355tts_unload": (C.c_int, [_VP, C.c_int]),
     "mi355tts_model_set_precision": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "mi355tts_broadcast_weights": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int64, C.c_char_p]),
     "mi355tts_glow_infer": (
         C.c_int,
         [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,

@@ -418,3 +418,50 @@ def test_plain_bf16_mode_documented_tolerance(gpu_engine):
         out[name] = float(np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)))
     print("plain bf16 rms", out["bf16"], "split rms", out["bf16x3"])
     assert out["bf16"] <= 1e-2 and out["bf16x3"] <= 1e-4 and out["bf16"] > 20 * out["bf16x3"]
+
+
+def test_broadcast_weights_over_a_callers_rccl_communicator(gpu_engine):
+    """`mi355tts_broadcast_weights`: the caller owns an RCCL communicator — here a one-rank
+    one made with ctypes on the system's librccl —, the folded weight blob sits in device memory, the library
+    broadcasts it in place and loads the model from the device buffer."""
+    import ctypes
+
+    import torch
+
+    from larynx_amd import ffi
+
+    path = "/opt/rocm/lib/librccl.so"
+    try:
+        rccl = ctypes.CDLL(path)
+    except OSError:
+        pytest.skip("no system RCCL library")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        hp = HP.HIFIGAN_LOW
+        sd = synthetic.make_hifigan_state_dict(hp, seed=1234)
+        blob = gpu_engine.hifigan_blob(hp, sd)
+        t = torch.from_numpy(blob).cuda()
+        torch.cuda.synchronize()
+        gpu_engine.broadcast_weights(comm.value, 0, t.data_ptr(), blob.size, rccl_library=path)
+        assert np.array_equal(t.cpu().numpy(), blob)
+        v_dev = gpu_engine.load_hifigan(hp, device_ptr=t.data_ptr())
+        _, (_, v_host) = models(gpu_engine, HP.LJSPEECH, hp)
+        melin = (np.random.default_rng(3).standard_normal((1, 80, 40)) * 2).astype(np.float32)
+        a, _ = gpu_engine.hifigan_infer(v_dev, gpu_engine.mel_from_numpy(melin))
+        b, _ = gpu_engine.hifigan_infer(v_host, gpu_engine.mel_from_numpy(melin))
+        assert np.array_equal(a, b)
+        gpu_engine.unload(v_dev)
+        with pytest.raises(ffi.Mi355ttsError):
+            gpu_engine.broadcast_weights(0, 0, t.data_ptr(), blob.size)
+    finally:
+        rccl.ncclCommDestroy(comm)
