@@ -123,6 +123,34 @@ int main(int argc, char** argv) {
       if (i >= frames[b] * hop && (wav[(size_t)b * wav_ld + i] != 0.0f || pcm[(size_t)b * wav_ld + i] != 0)) { fprintf(stderr, "tail not zero\n"); return 1; }
     }
   }
+  /* round-2 entry points: workers reserved up front; the fused one-call form with SSML pause padding must give the
+   * two-call result shifted by pad_before; an output row that is too small is refused with the frame counts
+   * filled in; the precision switch is accepted by both kinds of model and rejects unknown values */
+  CHECK(mi355tts_reserve(ctx, 2, glow, voc, B, LD, 64, 0, 16));
+  {
+    enum { PB = 5, PA = 3 };
+    const int64_t ld2 = wav_ld + PB + PA;
+    int16_t* pcm2 = (int16_t*)calloc((size_t)(B * ld2), sizeof(int16_t));
+    int32_t fr2[B] = {0, 0};
+    CHECK(mi355tts_synthesize(ctx, glow, voc, &ids[0][0], lens, B, LD, 0.0f, 1.0f, NULL, 0, 1u, &audio, 0.0f, PB, PA, fr2, NULL, pcm2, ld2, 0u));
+    for (b = 0; b < B; ++b) {
+      if (fr2[b] != frames[b]) { fprintf(stderr, "fused call: frame count differs\n"); return 1; }
+      for (i = 0; i < ld2; ++i) {
+        const int j = i - PB;
+        const int16_t want = (j >= 0 && j < wav_ld) ? pcm[(size_t)b * wav_ld + j] : 0;
+        if (pcm2[(size_t)b * ld2 + i] != want) { fprintf(stderr, "fused call differs at row %d sample %d\n", b, i); return 1; }
+      }
+    }
+    fr2[0] = fr2[1] = -1;
+    if (mi355tts_synthesize(ctx, glow, voc, &ids[0][0], lens, B, LD, 0.0f, 1.0f, NULL, 0, 1u, &audio, 0.0f, PB, PA, fr2, NULL, pcm2, 8, 0u) !=
+            MI355TTS_ERR_TOO_SMALL || fr2[0] != frames[0] || fr2[1] != frames[1]) { fprintf(stderr, "short fused row not reported\n"); return 1; }
+    free(pcm2);
+  }
+  CHECK(mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_BF16X3));
+  CHECK(mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_F32));
+  CHECK(mi355tts_model_set_precision(ctx, glow, MI355TTS_PRECISION_BF16X3));
+  if (mi355tts_model_set_precision(ctx, voc, 99) == 0) { fprintf(stderr, "unknown precision accepted\n"); return 1; }
+  if (mi355tts_broadcast_weights(ctx, NULL, 0, NULL, 0, NULL) == 0) { fprintf(stderr, "null communicator accepted\n"); return 1; }
   printf("frames %d %d mel_sum %.6e wav_sum %.6e pcm_sum %ld\n", (int)frames[0], (int)frames[1], mel_sum, wav_sum, pcm_sum);
   mi355tts_mel_free(mel);
   CHECK(mi355tts_unload(ctx, glow));
