@@ -51,9 +51,13 @@ constexpr int conv_bf16_lds_units() {
   return 2 * 2 * 4 * (32 * NB * WN + HALO);
 }
 
-template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS>
+// KS = 2 splits the K-dim between two groups of waves — group kg takes slab kg of every 32-channel chunk — and sums
+// the two partial tiles through LDS: launches with too few tiles to fill the chip (stage 0 of 'high' at batch 1:
+// 256 channels x 4992 columns = 78 tiles of 128 x 128 per conv) then put 8 waves on every tile instead of 4.
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1>
 __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, uint4* __restrict__ xs) {
-  constexpr int NWAVES = WM * WN;
+  static_assert(KS == 1 || KS == 2, "k-split of the bf16 tile is 1 or 2");
+  constexpr int NWAVES = WM * WN * KS;
   constexpr int NT = 64 * NWAVES;
   constexpr int T_T = 32 * NB * WN;   // time columns per workgroup
   constexpr int XW = T_T + HALO;      // staged columns per octet row
@@ -69,7 +73,8 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave % WM;
-  const int wn = wave / WM;
+  const int wn = (wave / WM) % WN;
+  const int kg = wave / (WM * WN);
   const int t0 = tile_x * T_T;
   const int mt0 = (tile_y * WM + wm) * MB;
 
@@ -87,8 +92,7 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
   // ---- staging: unit (octet o, column quad q) = 8 channels x 4 columns, eight 16-byte loads (one per
   // channel, coalesced along time), split into bf16 hi/lo and stored column by column as 16-byte
   // [8 channels] groups.  The loads of chunk c+1 are issued before chunk c's MFMA phase and consumed after it.
-  float4 pre[NU][8];
-  auto gload = [&](int chunk) {
+  auto gload = [&](int chunk, float4 (&pre)[NU][8]) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int u = tid + NT * i;
@@ -102,7 +106,12 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
       }
     }
   };
-  auto lstore = [&](int buf, int chunk) {
+  // leaky ReLU as max(v, v * slope) when 0 <= slope <= 1 (two VALU ops instead of three; same bits for finite v)
+  const bool slope01 = slope >= 0.f && slope <= 1.f;
+  // a tile whose staged window lies inside the row needs no column masks (the common case by far)
+  const bool cols_inside = t0 - PA >= 0 && t0 - PA + XW <= Lin;
+  auto lstore = [&](int buf, int chunk, const float4 (&pre)[NU][8]) {
+    const bool inside = cols_inside && slope01 && chunk * 32 + 32 <= a.Cin;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int u = tid + NT * i;
@@ -110,16 +119,27 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
       const int o = u / XQ, q = u - o * XQ;
       const int c0 = t0 - PA + 4 * q;
       float v[8][4];
+      if (inside) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool cok = chunk * 32 + 8 * o + j < a.Cin;
-        const float4 p = pre[i][j];
-        v[j][0] = (cok && c0 >= 0 && c0 < Lin) ? p.x : 0.f;
-        v[j][1] = (cok && c0 + 1 >= 0 && c0 + 1 < Lin) ? p.y : 0.f;
-        v[j][2] = (cok && c0 + 2 >= 0 && c0 + 2 < Lin) ? p.z : 0.f;
-        v[j][3] = (cok && c0 + 3 >= 0 && c0 + 3 < Lin) ? p.w : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const float4 p = pre[i][j];
+          v[j][0] = fmaxf(p.x, p.x * slope);
+          v[j][1] = fmaxf(p.y, p.y * slope);
+          v[j][2] = fmaxf(p.z, p.z * slope);
+          v[j][3] = fmaxf(p.w, p.w * slope);
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * slope;
+        for (int j = 0; j < 8; ++j) {
+          const bool cok = chunk * 32 + 8 * o + j < a.Cin;
+          const float4 p = pre[i][j];
+          v[j][0] = (cok && c0 >= 0 && c0 < Lin) ? p.x : 0.f;
+          v[j][1] = (cok && c0 + 1 >= 0 && c0 + 1 < Lin) ? p.y : 0.f;
+          v[j][2] = (cok && c0 + 2 >= 0 && c0 + 2 < Lin) ? p.z : 0.f;
+          v[j][3] = (cok && c0 + 3 >= 0 && c0 + 3 < Lin) ? p.w : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * slope;
+        }
       }
       uint4* dst = xs + buf * BUF + o * XW + 4 * q;
 #pragma unroll
@@ -142,81 +162,151 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  float4 pre[NU][8];
 
   // A stream of m-tile mt: uint4 index (((mt*nslab + slab)*K + k)*2 + plane)*64 + lane
   const uint4* wq[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) wq[mb] = reinterpret_cast<const uint4*>(a.w16) + (long long)(mt0 + mb) * a.nslab * K * 128 + lane;
-  constexpr int S = 2 * K;  // steps per chunk: tap-major, two slabs per tap
+  constexpr int SPC = 2 / KS;  // slabs of a chunk this k-group walks
+  constexpr int S = SPC * K;   // steps per chunk: tap-major, SPC slabs per tap
   const int last_step = nchunks * S - 1;
   auto a_off = [&](int g) -> int {  // uint4 offset of global step g (clamped at the end: harmless re-load)
     g = g < last_step ? g : last_step;
     const int ch = g / S, st = g - ch * S;
-    const int k = st >> 1, s = st & 1;
+    const int k = st / SPC, s = KS == 2 ? kg : (st & 1);
     return ((ch * 2 + s) * K + k) * 128;
   };
-  uint4 Ahi[MB], Alo[MB], Nhi[MB], Nlo[MB];
+  // Operand pipeline of one wave (registers): weight fragments run AD steps ahead of the MFMAs that use them
+  // (Ah[0] = this step ... Ah[AD] = in flight for step + AD: an L2 hit costs more than one step of 12 MFMAs —
+  // measured -7 % going from one step ahead to two), LDS fragments ONE step ahead (B0 = this step, B1 = next).  The
+  // fillers are pinned behind individual MFMAs with sched_group_barrier — left alone the compiler sinks every load
+  // to just above its first use and the wave stalls once per step on LDS and once on L2 (-20 % on the class).
+#ifndef BF16_ADIST
+#define BF16_ADIST 2
+#endif
+  constexpr int AD = BF16_ADIST;
+  uint4 Ah[AD + 1][MB], Al[AD + 1][MB];
+  uint4 B0h[NB], B0l[NB], B1h[NB], B1l[NB];
 
-  gload(0);
+  gload(0, pre);
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    Ahi[mb] = wq[mb][a_off(0)];
-    Alo[mb] = wq[mb][a_off(0) + 64];
-  }
-  lstore(0, 0);
+  for (int d = 0; d < AD; ++d)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      Ah[d][mb] = wq[mb][a_off(d)];
+      if (TERMS == 3) Al[d][mb] = wq[mb][a_off(d) + 64];
+    }
+  lstore(0, 0, pre);
   __syncthreads();
 
   // this lane's B column inside the staged row, and its octet half
   const int colb = wn * (NB * 32) + (lane & 31) + (PA - a.pad);
   const int ohalf = lane >> 5;
+  constexpr int NMF = TERMS * MB * NB;  // MFMAs per step
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
     const bool more = chunk + 1 < nchunks;
-    if (more) gload(chunk + 1);
+    if (more) gload(chunk + 1, pre);
     const uint4* xt = xs + buf * BUF + colb;
-#pragma unroll
-    for (int st = 0; st < S; ++st) {
-      const int k = st >> 1, s = st & 1;
-      // next step's weight fragments go out first, this step's operands are already in registers
-      {
-        const int off = a_off(chunk * S + st + 1);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          Nhi[mb] = wq[mb][off];
-          if (TERMS == 3) Nlo[mb] = wq[mb][off + 64];
-        }
-      }
-      uint4 Bhi[NB], Blo[NB];
+    auto bread = [&](int st, uint4* bh, uint4* bl) {
+      const int k = st / SPC, s = KS == 2 ? kg : (st & 1);
       const uint4* bp = xt + (2 * s + ohalf) * XW + k * a.dil;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        Bhi[nb] = bp[nb * 32];
-        if (TERMS == 3) Blo[nb] = bp[PLANE + nb * 32];
+        bh[nb] = bp[nb * 32];
+        if (TERMS == 3) bl[nb] = bp[PLANE + nb * 32];
       }
+    };
+    bread(0, B0h, B0l);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      {
+        const int off = a_off(chunk * S + st + AD);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          Ah[AD][mb] = wq[mb][off];
+          if (TERMS == 3) Al[AD][mb] = wq[mb][off + 64];
+        }
+      }
+      if (st + 1 < S) bread(st + 1, B1h, B1l);
       // term-major order: consecutive MFMAs go to different accumulators
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ahi[mb], Bhi[nb], acc[mb][nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ah[0][mb], B0h[nb], acc[mb][nb]);
       if (TERMS == 3) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ahi[mb], Blo[nb], acc[mb][nb]);
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Ah[0][mb], B0l[nb], acc[mb][nb]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Alo[mb], Bhi[nb], acc[mb][nb]);
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_bf16(Al[0][mb], B0h[nb], acc[mb][nb]);
+      }
+      // issue order: one filler behind each MFMA (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
+      {
+        constexpr int NV = (TERMS == 3 ? 2 : 1) * MB, ND = (TERMS == 3 ? 2 : 1) * NB;
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          else if (st + 1 < S) {
+            // one LDS read behind each remaining MFMA, whatever is left over behind the last one
+            constexpr int R = NMF - NV;
+            const int j = i - NV;
+            const int cnt = j < R - 1 ? (j < ND ? 1 : 0) : (ND - (R - 1) > 0 ? ND - (R - 1) : (j < ND ? 1 : 0));
+            if (cnt == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (cnt == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (cnt == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            else if (cnt == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        Ahi[mb] = Nhi[mb];
-        if (TERMS == 3) Alo[mb] = Nlo[mb];
+      for (int d = 0; d < AD; ++d)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          Ah[d][mb] = Ah[d + 1][mb];
+          if (TERMS == 3) Al[d][mb] = Al[d + 1][mb];
+        }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        B0h[nb] = B1h[nb];
+        if (TERMS == 3) B0l[nb] = B1l[nb];
       }
     }
-    if (more) lstore(buf ^ 1, chunk + 1);
+    if (more) lstore(buf ^ 1, chunk + 1, pre);
     __syncthreads();
+  }
+
+  if constexpr (KS == 2) {
+    // sum the two k-groups' partial tiles through LDS (the staging buffers are free: the loop ended on a barrier),
+    // one column block per round; group 0 owns the epilogue
+    float* red = reinterpret_cast<float*>(xs);
+    static_assert(WM * WN * MB * 16 * 64 * 4 <= conv_bf16_lds_units<NB, WN, HALO>() * 16, "reduction scratch must fit the staging buffers");
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (nb > 0) __syncthreads();
+      if (kg == 1) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((wn * WM + wm) * MB + mb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][nb][r] += red[(((wn * WM + wm) * MB + mb) * 16 + r) * 64 + lane];
+      }
+    }
+    if (kg != 0) return;
   }
 
   // ---- epilogue: bias, residual, scale, accumulate; loads batched from clamped addresses
@@ -267,17 +357,20 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
   }
 }
 
-template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const ConvArgs a) {
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS) void conv_bf16_kernel(const ConvArgs a) {
   __shared__ uint4 xs[conv_bf16_lds_units<NB, WN, HALO>()];
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
-  conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS>(a, tile_x, tile_y, blockIdx.z, xs);
+  conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS, KS>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // The three MRF chains' same-geometry convs in ONE launch (see conv_group_kernel).
-template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int TERMS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_group_kernel(const ConvGroupArgs g) {
+template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int TERMS, int KS = 1>
+#ifndef BF16_OCC
+#define BF16_OCC 1
+#endif
+__global__ __launch_bounds__(64 * WM * WN * KS, (NB == 4 && KS == 1) ? BF16_OCC : 1) void conv_bf16_group_kernel(const ConvGroupArgs g) {
   constexpr int L0 = conv_bf16_lds_units<NB, WN, H0>(), L1 = conv_bf16_lds_units<NB, WN, H1>(), L2 = conv_bf16_lds_units<NB, WN, H2>();
   __shared__ uint4 xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
@@ -286,17 +379,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_group_kernel(const Con
   if (lin < g.off[1]) {
     if (lin >= g.gx[0] * g.gy[0]) return;
     xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
-    conv_bf16_tile<K0, MB, NB, WM, WN, H0, TERMS>(g.c[0], tx, ty, b, xs);
+    conv_bf16_tile<K0, MB, NB, WM, WN, H0, TERMS, KS>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
     if (l >= g.gx[1] * g.gy[1]) return;
     xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
-    conv_bf16_tile<K1, MB, NB, WM, WN, H1, TERMS>(g.c[1], tx, ty, b, xs);
+    conv_bf16_tile<K1, MB, NB, WM, WN, H1, TERMS, KS>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
     if (l >= g.gx[2] * g.gy[2]) return;
     xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
-    conv_bf16_tile<K2, MB, NB, WM, WN, H2, TERMS>(g.c[2], tx, ty, b, xs);
+    conv_bf16_tile<K2, MB, NB, WM, WN, H2, TERMS, KS>(g.c[2], tx, ty, b, xs);
   }
 }
 

@@ -125,6 +125,7 @@ enum Bf16Cfg {
   BF_B = 1,  // 4 x 1 waves, NB = 1: 128 rows x  32 columns (few-tile launches: stage 0 of 'high' at batch 1; measured 2 % better than 64 columns)
   BF_C = 2,  // 2 x 2 waves, NB = 2:  64 rows x 128 columns (64-channel stages)
   BF_D = 3,  // 1 x 4 waves, NB = 1:  32 rows x 128 columns (32-channel stages; 256 columns would need 85 KB of LDS)
+  BF_K = 4,  // 4 x 1 waves x 2 k-groups, NB = 4: 128 rows x 128 columns by 8 waves (few-tile launches with >= 64 channels in)
 };
 
 // `a` arrives with every tensor/epilogue field filled; this picks the tile and
@@ -162,9 +163,10 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     int cfg, rows_t, cols_t;
     if (c.mtiles16 % 4 == 0) {
       const long long tiles_a = (long long)((n_max + 127) / 128) * (c.mtiles16 / 4) * B;
-      cfg = tiles_a >= 256 ? BF_A : BF_B;
+      static const bool no_k = [] { const char* e = std::getenv("MI355TTS_NO_BF_K"); return e && std::atoi(e) != 0; }();
+      cfg = tiles_a >= 256 ? BF_A : (no_k ? BF_B : BF_K);
       rows_t = 128;
-      cols_t = cfg == BF_A ? 128 : 32;
+      cols_t = cfg == BF_B ? 32 : 128;
     } else if (c.mtiles16 == 2) {
       cfg = BF_C;
       rows_t = 64;
@@ -269,6 +271,7 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a);      \
   else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
   else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 2, 2, 2, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
+  else if (shape == BF_K) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT, 2>), grid, dim3(512), 0, s, a); \
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 1, 4, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a)
 #define BF16_LAUNCH(KK)            \
   if (p.bf16 == 3) {               \
@@ -388,6 +391,9 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   else if (p0.shape == BF_C)                                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 2, 2, 2, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g);                                                                                                  \
+  else if (p0.shape == BF_K)                                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT, 2>), \
+                       grid, dim3(512), 0, s, g);                                                                                                  \
   else                                                                                                                                             \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 1, 1, 4, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
                        grid, dim3(256), 0, s, g)
