@@ -417,6 +417,15 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   return launch_group_k<7, 5, 3>(s, p0.MB, p0.shape, grid, g);
 }
 
+// Tile of the fused split-bf16 pair kernel (resblock_pair_bf16.h): time-waves x column blocks per wave, 256 columns in all
+#ifndef P16_WN64
+#define P16_WN64 4
+#define P16_NB64 2
+#endif
+#ifndef P16_WN32
+#define P16_WN32 4
+#define P16_NB32 2
+#endif
 // Fused ResBlock1 step (conv1 -> lrelu -> conv2 -> + x) for the 32/64-channel stages.
 struct PairPlan {
   PairArgs a;
@@ -424,6 +433,7 @@ struct PairPlan {
   dim3 grid;
   double flop = 0;
   bool ok = false;  // geometry covered by the fused kernel
+  int bf16 = 0;     // 0 = f32 kernel (resblock_pair.h); 3 / 1 = split / plain bf16 kernel (resblock_pair_bf16.h)
 };
 static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs, int ld, const int* len,
                       int len_mul, int dil, float alpha, int accum, int B, int Lmax, int host_len, PairPlan* out, int precision = 0) {
@@ -431,7 +441,11 @@ static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, floa
   const int nb64 = 1;  // measured: 128-column tiles beat 256 at C = 64 (163 vs 197 us for the k = 11 pair)
   const int C = c1.Cout, K = c1.K;
   out->ok = false;
-  if (precision != MI355TTS_PRECISION_F32 && c1.w16 && c2.w16) return;  // the bf16 modes run these convs un-fused on the bf16 cores
+  const bool half = precision != MI355TTS_PRECISION_F32 && c1.w16 && c2.w16;
+  if (half) {
+    static const bool no_fused = [] { const char* e = std::getenv("MI355TTS_NO_BF16_PAIR"); return e && std::atoi(e) != 0; }();
+    if (no_fused || c1.nslab16 != C / 16 || c2.nslab16 != C / 16 || c1.mtiles16 != C / 32 || c2.mtiles16 != C / 32) return;  // un-fused bf16 convs
+  }
   if (off || (C != 32 && C != 64) || c1.Cin != C || c2.Cin != C || c2.Cout != C || c2.K != K || dil > PAIR_DMAX || dil < 1 ||
       (K != 3 && K != 7 && K != 11) || c1.noct != c2.noct || !c1.has_bias || !c2.has_bias || (ld % 4) || x == y || Lmax <= 0)
     return;
@@ -455,7 +469,11 @@ static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, floa
   a.accum = accum;
   out->K = K;
   out->C = C;
-  out->NB = (C == 32) ? 2 : nb64;
+  out->NB = (C == 32 || half) ? 2 : nb64;
+  out->bf16 = half ? (precision == MI355TTS_PRECISION_BF16 ? 1 : 3) : 0;
+  a.w1h = c1.w16;
+  a.w2h = c2.w16;
+  a.nslab = c1.nslab16;
   const int T2 = 128 * out->NB - (K - 1);
   out->grid = dim3((Lmax + T2 - 1) / T2, 1, B);
   out->flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
@@ -465,6 +483,23 @@ static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t
   ProfScope ps(ctx, w, KC_RESBLOCK, p.flop, s);
   const PairArgs& a = p.a;
   const dim3 grid = p.grid;
+  if (p.bf16) {
+#define PAIR16_LAUNCH(KK, TT)                                                                                                                  \
+  if (p.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_kernel<KK, 1, P16_WN32, P16_NB32, TT>), grid, dim3(64 * P16_WN32), 0, s, a);     \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_kernel<KK, 2, P16_WN64, P16_NB64, TT>), grid, dim3(128 * P16_WN64), 0, s, a)
+#define PAIR16_K(KK)          \
+  if (p.bf16 == 3) {          \
+    PAIR16_LAUNCH(KK, 3);     \
+  } else {                    \
+    PAIR16_LAUNCH(KK, 1);     \
+  }
+    if (p.K == 3) { PAIR16_K(3); }
+    else if (p.K == 7) { PAIR16_K(7); }
+    else { PAIR16_K(11); }
+#undef PAIR16_K
+#undef PAIR16_LAUNCH
+    return 0;
+  }
 #define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
 #define PAIR_K(KK)                                  \
   if (p.C == 32) PAIR_LAUNCH(KK, 1, 2);             \
@@ -488,10 +523,10 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   const PairPlan& p0 = plans[ord[0]];
   for (int i = 0; i < 3; ++i) {
     const PairPlan& p = plans[ord[i]];
-    if (!p.ok || p.C != p0.C || p.NB != p0.NB || p.grid.z != p0.grid.z) return 1;
+    if (!p.ok || p.C != p0.C || p.NB != p0.NB || p.grid.z != p0.grid.z || p.bf16 != p0.bf16) return 1;
   }
   if (!(plans[ord[0]].K == 11 && plans[ord[1]].K == 7 && plans[ord[2]].K == 3)) return 1;
-  if (!((p0.C == 32 && p0.NB == 2) || (p0.C == 64 && p0.NB == 1))) return 1;
+  if (!p0.bf16 && !((p0.C == 32 && p0.NB == 2) || (p0.C == 64 && p0.NB == 1))) return 1;
   PairGroupArgs g;
   double flop = 0;
   int off_wg = 0;
@@ -506,6 +541,16 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   g.off[3] = off_wg;
   const dim3 grid(off_wg, 1, p0.grid.z);
   ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+  if (p0.bf16 == 3) {
+    if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 1, P16_WN32, P16_NB32, 3>), grid, dim3(64 * P16_WN32), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 2, P16_WN64, P16_NB64, 3>), grid, dim3(128 * P16_WN64), 0, s, g);
+    return 0;
+  }
+  if (p0.bf16 == 1) {
+    if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 1, P16_WN32, P16_NB32, 1>), grid, dim3(64 * P16_WN32), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 2, P16_WN64, P16_NB64, 1>), grid, dim3(128 * P16_WN64), 0, s, g);
+    return 0;
+  }
   if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 1, 2>), grid, dim3(512), 0, s, g);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 2, 1>), grid, dim3(512), 0, s, g);
   return 0;

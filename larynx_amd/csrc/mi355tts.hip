@@ -27,6 +27,7 @@
 #include "conv_mfma.h"
 #include "resblock_pair.h"
 #include "conv_bf16.h"
+#include "resblock_pair_bf16.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 

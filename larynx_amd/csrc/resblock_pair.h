@@ -40,6 +40,10 @@ struct PairArgs {
   float slope;
   float alpha;  // y = [y +] alpha * (...): the serial MRF schedule accumulates here
   int accum;
+  // split-bf16 form of the same step (resblock_pair_bf16.h): weights packed by pack_conv_bf16, slabs per m-tile
+  const void* w1h = nullptr;
+  const void* w2h = nullptr;
+  int nslab = 0;
 };
 
 constexpr int PAIR_DMAX = 5;  // largest conv1 dilation the staged halo covers

@@ -303,6 +303,21 @@ def test_bf16x3_mode_64_and_32_channel_stages(emu_engine):
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
     check_bf16x3_mode(emu_engine, hp, 85, [150, 37], 1e-4)
+    # these stages run conv1 -> lrelu -> conv2 -> + x as ONE kernel in this mode too (csrc/resblock_pair_bf16.h):
+    # 2 stages x 2 dilations grouped launches of fused pairs (un-fused it would be 8)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=85)
+    v = emu_engine.load_hifigan(hp, sd)
+    mb = emu_engine.mel_from_numpy(np.zeros((1, hp.num_mels, 150), np.float32), np.array([150], np.int32))
+    emu_engine.set_precision(v, ffi.PRECISION_BF16X3)
+    emu_engine.set_profiling(True)
+    emu_engine.profile_reset()
+    try:
+        emu_engine.hifigan_infer(v, mb)
+        launches = emu_engine.profile()["conv_mfma.hifigan_resblock"]["launches"]
+    finally:
+        emu_engine.set_profiling(False)
+        emu_engine.unload(v)
+    assert launches == 4
 
 
 def test_plain_bf16_mode(emu_engine):
