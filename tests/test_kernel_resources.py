@@ -17,13 +17,28 @@ def resources(tmp_path_factory):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).is_file():
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("res") / "dev.o"
-    proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
-                           "-Rpass-analysis=kernel-resource-usage", str(SRC), "-o", str(out)],
-                          capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0, proc.stderr[-2000:]
+    # the remarks of one source state are kept under build/ (git-ignored): the device compile takes two minutes
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted(SRC.parent.glob("*")) + [REPO / "include" / "mi355tts.h"]:
+        h.update(f.read_bytes())
+    cache = REPO / "build" / f"kernel_resources_{h.hexdigest()[:12]}.txt"
+    if cache.is_file():
+        remarks = cache.read_text()
+    else:
+        out = tmp_path_factory.mktemp("res") / "dev.o"
+        proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
+                               "-Rpass-analysis=kernel-resource-usage", str(SRC), "-o", str(out)],
+                              capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        remarks = proc.stderr
+        cache.parent.mkdir(exist_ok=True)
+        for old in cache.parent.glob("kernel_resources_*.txt"):
+            old.unlink()
+        cache.write_text(remarks)
     table = {}
-    for block in re.split(r"remark: [^\n]*Function Name: ", proc.stderr)[1:]:
+    for block in re.split(r"remark: [^\n]*Function Name: ", remarks)[1:]:
         name = block.split()[0]
 
         def num(key):
