@@ -210,18 +210,33 @@ def main():
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        pg_note = None
         try:
             if on_gpu:
-                dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+                try:
+                    if os.environ.get("BENCH_SIMULATE_RCCL_FAILURE"):  # exercises the fallback below on a healthy node
+                        raise RuntimeError("simulated (BENCH_SIMULATE_RCCL_FAILURE)")
+                    dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                except Exception as e:  # noqa: BLE001 - the data path has no collective: a host-side group is enough to time it
+                    # RCCL could not come up on this node: keep the job alive on gloo (barriers and the max-over-ranks
+                    # reductions go over the host), every rank folds its own copy of the seeded weights
+                    pg_note = f"{type(e).__name__}: {str(e).splitlines()[0][:160] if str(e) else ''}"
+                    print(f"[bench] RCCL process group failed ({pg_note}); falling back to gloo", file=sys.stderr)
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                    dist.init_process_group("gloo")
+                    dist.barrier()
             else:
                 dist.init_process_group("gloo")
-            dist.barrier()
-            if on_gpu:
-                torch.cuda.synchronize()
+                dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    rccl = use_dist and on_gpu and dist.get_backend() == "nccl"
+    red_dev = dev if (rccl or not use_dist) else torch.device("cpu")  # where the timing reductions live
 
     def sync():
         if on_gpu:
@@ -242,14 +257,14 @@ def main():
     man_v = ffi.manifest(eng.lib, ffi.hifigan_hparams_c(vhp))
     n_g, n_v = sum(n for _, n in man_g), sum(n for _, n in man_v)
     blob = torch.empty(n_g + n_v, dtype=torch.float32, device=dev)
-    if rank == 0:
+    if rank == 0 or (use_dist and on_gpu and not rccl):
         from larynx_amd.weights import build_blob
 
         bg = build_blob(man_g, synthetic.make_glow_state_dict(ghp, seed=1234))
         bv = build_blob(man_v, synthetic.make_hifigan_state_dict(vhp, seed=1234))
         blob.copy_(torch.from_numpy(np.concatenate([bg, bv])))
     t_b = time.perf_counter()
-    if use_dist:
+    if use_dist and (rccl or not on_gpu):
         dist.broadcast(blob, src=0)
     sync()
     broadcast_s = time.perf_counter() - t_b
@@ -386,7 +401,7 @@ def main():
         half = (med(h_flight), med(h_single), hprof["conv_mfma.hifigan_resblock"])
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
-                          half[0] if half else 0.0, half[1] if half else 0.0], dtype=torch.float64, device=dev)
+                          half[0] if half else 0.0, half[1] if half else 0.0], dtype=torch.float64, device=red_dev)
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -441,7 +456,7 @@ def main():
         t0 = time.perf_counter()
         merged = sharding.gather_in_order(local_out, len(rows)) if use_dist else [local_out[i] for i in range(len(rows))]
         t_gather = time.perf_counter() - t0
-        tj = torch.tensor([t_job], dtype=torch.float64, device=dev)
+        tj = torch.tensor([t_job], dtype=torch.float64, device=red_dev)
         if use_dist:
             dist.all_reduce(tj, op=dist.ReduceOp.MAX)
         if rank == 0:
@@ -495,7 +510,7 @@ def main():
                 total5 += a5.shape[0]
             barrier()
             t5 = time.perf_counter() - t0
-        st5 = torch.tensor([t5, first, float(total5)], dtype=torch.float64, device=dev)
+        st5 = torch.tensor([t5, first, float(total5)], dtype=torch.float64, device=red_dev)
         if use_dist:
             mx5 = st5.clone()
             dist.all_reduce(mx5, op=dist.ReduceOp.MAX)
@@ -591,7 +606,7 @@ def main():
                 "resblock_class_f32_equivalent_tflops": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 if half[2]["ms"] > 0 else None,
             },
             "weight_broadcast_seconds": broadcast_s if use_dist else None,
-            "process_group": ("nccl (RCCL)" if on_gpu else "gloo") if use_dist else None,
+            "process_group": (("nccl (RCCL)" if rccl else ("gloo" if not on_gpu else f"gloo (RCCL init failed: {pg_note}); every rank folded its own seeded weights")) if use_dist else None),
             "roofline": {
                 "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (fused conv pairs, 64/32-channel stages)",
                 "bound": "mfma",
