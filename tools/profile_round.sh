@@ -9,10 +9,10 @@ OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config5 --no-half-mode --concurrency 1 --repeats 1"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH > $OUT/bench_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq -o sq --output-format csv -- $BENCH > $OUT/bench_sq.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- $BENCH > $OUT/bench_fetch.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- $BENCH > $OUT/bench_write.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq -o sq --output-format csv -- $BENCH > $OUT/bench_sq.log 2>&1
 ls -R $OUT | head -40
 # keep the merged-back payload small: counter CSVs can be large
 for f in $OUT/*/*counter_collection.csv; do python tools/pmc_reduce.py $f > ${f%.csv}_by_kernel.csv; rm -f $f; done
