@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=1500)
     ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--no-reserve", action="store_true", help="leave the workspaces grow-only (no mi355tts_reserve up front)")
     args = ap.parse_args()
     eng = Engine(0)
     s = ljspeech_audio_settings()
@@ -52,6 +53,13 @@ def main():
         B = 1 if rng.random() < 0.8 else int(rng.integers(2, 5))
         rows = [synthetic.synthetic_phoneme_ids(rng, int(rng.integers(1, 220)), ghp.num_symbols) for _ in range(B)]
         jobs.append((i, g, v, vhp, rows, 0.01 if rng.random() < 0.2 else 0.0, bool(rng.random() < 0.4)))
+
+    # every worker a call can land on exists and is sized for the largest job before the first pass (mi355tts_reserve):
+    # VRAM use must then be FLAT from pass 1 on.  (Without it the per-worker workspaces are grow-only and keep
+    # rising until every worker has met the largest job.)
+    if not args.no_reserve:
+        eng.reserve(args.threads + 1, voices[0][1], vocs[0][1], max_batch=4, max_ids=220, max_frames=220 * 12, denoiser=True,
+                    max_pad_samples=2 * 37 + 11)
 
     def run(job):
         i, g, v, vhp, rows, dn, fused = job
@@ -105,7 +113,7 @@ def main():
         eng.unload(v)
     eng.close()
     print(json.dumps({"calls": args.calls, "threads": args.threads, "seconds": dt, "calls_per_s": args.calls / dt,
-                      "vram_used_before": used0, "vram_used_after_each_pass": trail,
+                      "reserved_up_front": not args.no_reserve, "vram_used_before": used0, "vram_used_after_each_pass": trail,
                       "growth_last_pass_bytes": trail[-1] - trail[-2]}))
 
 
