@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the headline pass with the MRF chains on one stream too (for rocprofv3 kernel traces)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = the emulator build (tests only)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE", help="mi355tts_set_option before anything runs (A/B of schedules)")
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
@@ -248,6 +249,8 @@ def main():
         sync()
 
     eng = Engine(device=local if on_gpu else 0, library_path=args.library)
+    for kv in args.set_option:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.tiny:
         ghp, vhp, quality = HP.TINY_GLOW, HP.TINY_HIFIGAN, "tiny"
     else:

@@ -224,8 +224,11 @@ int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, in
 int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
 /* options: "serial_branches" (0/1) — run the three MRF ResBlock chains of a
  * HiFi-GAN stage one after another on one stream instead of concurrently on
- * three (used when timing single kernels); "adaptive_schedule" (0/1, default 1) —
- * fork the MRF chains onto side streams only while no other call is in flight. */
+ * three (used when timing single kernels); "mrf_group" (0/1, default 1) — the
+ * same-geometry launches of the three chains go out as one grouped launch; "adaptive_schedule"
+ * (0/1, default 0) — while other calls are in flight, launch the members of a group one by one
+ * (and, with "mrf_group" = 0, do not fork the chains onto side streams).  Results are the same bits
+ * under every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);

@@ -177,9 +177,10 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   // one grouped launch (conv_group_kernel / pair_group_kernel) — the chip is filled from one launch, with
   // no stream fork/join and independently of what else is in flight.  "mrf_group" = 0 restores the
   // round-1 schedule (fork onto three streams while the call has the GPU to itself).
-  // With other calls in flight (`adaptive_schedule`) the members go out one by one instead: many small
-  // launches from several streams interleave better than a few big ones (+3 % utterances/s at 6 calls in
-  // flight).  Every form runs the same tiles with the same code: results do not depend on the load.
+  // "adaptive_schedule" = 1 sends the members out one by one while other calls are in flight.  That was worth
+  // +3 % utterances/s at 6 calls in flight with the round-2 mid-way kernels; with the final tiles the grouped
+  // launch wins under load too (f32 +1.3 %, split-bf16 +5 %, same box), so the option is off by default.
+  // Every form runs the same tiles with the same code: results do not depend on the load.
   const bool busy = ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1;
   const bool grouped = split_out && nk == 3 && ctx->mrf_group && !busy;
   const bool concurrent = split_out && !ctx->mrf_group && !busy;

@@ -40,10 +40,10 @@ struct mi355tts_ctx {
   std::vector<Worker*> all_workers;
   bool profiling = false;
   bool serial_branches = false;
-  // calls currently holding a worker; with more than one in flight the vocoder keeps each
-  // call on ONE stream (the other calls fill the chip) instead of forking its MRF chains
+  // calls currently holding a worker; with "adaptive_schedule" on and more than one in flight the vocoder
+  // launches the members of a grouped step one by one (and never forks its MRF chains)
   std::atomic<int> active_calls{0};
-  bool adaptive_schedule = true;
+  bool adaptive_schedule = false;
   bool mrf_group = true;  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
