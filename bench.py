@@ -147,10 +147,12 @@ def main():
     ap.add_argument("--quality", default="high")
     ap.add_argument("--length-scale", type=float, default=0.65,
                     help="GlowTTS length_scale; 0.65 puts the synthetic 120-id utterances at SURVEY's standard ~620 frames")
-    ap.add_argument("--concurrency", type=int, default=6,
+    ap.add_argument("--concurrency", type=int, default=8,
                     help="utterances in flight per GPU in the timed region (host threads, each batch-1 call on its own "
-                         "HIP streams — the reference's ThreadPoolExecutor pattern); the single-stream latency is "
-                         "measured with the same method and reported next to it")
+                         "HIP stream — the reference's ThreadPoolExecutor pattern); the single-stream latency is "
+                         "measured with the same method and reported next to it.  A multiple of the runtime's 4 hardware "
+                         "queues: 5-7 streams load the queues unevenly (measured 4 / 8: 249 / 248 utterances/s, 5 / 6 / 7: "
+                         "242-244; split-bf16 mode 529 / 525 vs 494-502)")
     ap.add_argument("--batch", type=int, default=1,
                     help="utterances per call (rows of one padded batch). Default 1 = BASELINE.json's quoted configuration")
     ap.add_argument("--repeats", type=int, default=0,
@@ -281,8 +283,9 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     K, W = args.steps, args.warmup
     n_utts = K + W  # steps; each step is one call over `batch` utterances
+    n_rows = max(n_utts, max(1, args.concurrency))  # the warm-up runs one utterance on every in-flight slot
     B = max(1, args.batch)
-    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(n_utts * B)])
+    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(n_rows * B)])
     ids_dev = torch.from_numpy(ids_host).to(dev)
     lens = np.full(B, args.ids, np.int32)
     hop = vhp.hop
