@@ -72,17 +72,23 @@ def test_reserve_then_calls_do_not_grow(emu_engine, tiny):
 
 
 def check_schedule_invariance(eng, v, num_mels, frames=33, threads=4):
-    """The vocoder forks its MRF chains onto side streams only while it has the GPU to
-    itself (`adaptive_schedule`); results must not depend on which form ran, nor on how many
-    calls are in flight."""
+    """Grouped launches of the MRF chains (default), the members one by one while other calls are in flight
+    (`adaptive_schedule`), the round-1 fork onto side streams (`mrf_group` = 0): results must not depend on
+    which form ran, nor on how many calls are in flight."""
     rng = np.random.default_rng(17)
     melin = (rng.standard_normal((1, num_mels, frames)) * 2).astype(np.float32)
     outs = {}
-    for adaptive in (0, 1):
-        eng.set_option("adaptive_schedule", adaptive)
-        outs[adaptive] = eng.hifigan_infer(v, eng.mel_from_numpy(melin))[0]
-    eng.set_option("adaptive_schedule", 1)
-    assert np.array_equal(outs[0], outs[1])
+    try:
+        for adaptive, group in ((0, 1), (1, 1), (0, 0), (1, 0)):
+            eng.set_option("adaptive_schedule", adaptive)
+            eng.set_option("mrf_group", group)
+            outs[(adaptive, group)] = eng.hifigan_infer(v, eng.mel_from_numpy(melin))[0]
+    finally:
+        eng.set_option("adaptive_schedule", 0)  # the defaults
+        eng.set_option("mrf_group", 1)
+    outs[0] = outs[(0, 1)]
+    for k, o in outs.items():
+        assert np.array_equal(o, outs[0]), k
     got = [None] * threads
     gate = threading.Barrier(threads)
 
@@ -202,11 +208,11 @@ def check_grouped_schedule(eng, hp, seed, frames):
     try:
         forked, _ = eng.hifigan_infer(v, mb)
         n_forked = eng.profile()["conv_mfma.hifigan_resblock"]["launches"]
-        eng.set_option("adaptive_schedule", 0)
+        eng.set_option("adaptive_schedule", 1)
         forked2, _ = eng.hifigan_infer(v, mb)
     finally:
         eng.set_option("mrf_group", 1)
-        eng.set_option("adaptive_schedule", 1)
+        eng.set_option("adaptive_schedule", 0)
         eng.set_profiling(False)
     assert np.array_equal(grouped, forked) and np.array_equal(grouped, forked2)
     assert n_forked == 3 * n_grouped, (n_forked, n_grouped)  # every step of the three chains became one launch

@@ -216,6 +216,13 @@ def test_host_feature_checks_on_the_device(gpu_engine):
     check_synthesize_equals_two_calls(gpu_engine, g, v, HP.LJSPEECH.num_symbols, HP.HIFIGAN_MEDIUM.hop, lens=(40, 17, 63))
     _, (_, vh) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
     check_schedule_invariance(gpu_engine, vh, 80, frames=150, threads=6)
+    from larynx_amd import ffi
+
+    gpu_engine.set_precision(vh, ffi.PRECISION_BF16X3)  # the split-bf16 kernels (k-split tile, fused pairs) under the same schedules
+    try:
+        check_schedule_invariance(gpu_engine, vh, 80, frames=150, threads=6)
+    finally:
+        gpu_engine.set_precision(vh, ffi.PRECISION_F32)
     gpu_engine.reserve(4, g, vh, max_batch=1, max_ids=128, max_frames=1024, denoiser=True, max_pad_samples=22050)
 
 
