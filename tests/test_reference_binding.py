@@ -245,6 +245,12 @@ def test_hip_backend_equals_the_references_own_torch_backend(ref_larynx, voices,
     for a, b in zip(ref, hip):
         assert a.shape == b.shape and a.dtype == b.dtype == np.int16
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+    # the reference's own acceptance check for this path (tests/test_text_to_speech.py:76-105, `check_voice`): the
+    # concatenated audio is not silence (mean square > 25 on the int16 scale) and its duration is within 1 s of the
+    # expected one — here the reference backend's own output stands in for the sample WAV of a released voice
+    all_hip, all_ref = np.concatenate(hip).astype(np.float64), np.concatenate(ref).astype(np.float64)
+    assert (all_hip ** 2).sum() / len(all_hip) > 25.0
+    assert abs(all_hip.shape[-1] / 22050 - all_ref.shape[-1] / 22050) <= 1.0
 
 
 def test_reference_sentence_task_with_mixed_models(ref_larynx, voices, emu_library_path, monkeypatch):
