@@ -105,56 +105,17 @@ def test_unrecognised_layouts_fail_loudly(tmp_path):
 @pytest.mark.parametrize("opset,fold,keep", [(11, True, False), (13, False, True), (17, True, False)])
 def test_exporter_variants_from_the_reference_modules(emu_library_path, tmp_path, opset, fold, keep):
     """Other exporter settings than the committed fixture's (opset 12, folding on): older / newer opsets, constant
-    folding off, initializers kept as graph inputs — exported here from the reference's own modules (skipped where
-    /root/reference does not exist, e.g. on the GPU box).  All 20 combinations of opset {11, 12, 13, 14, 17} x folding x
+    folding off, initializers kept as graph inputs — exported from the reference's own modules by
+    `tests/onnx_variants_check.py` in a process of its own (it imports the reference tree; skipped where /root/reference
+    does not exist, e.g. on the GPU box).  All 20 combinations of opset {11, 12, 13, 14, 17} x folding x
     keep_initializers_as_inputs were checked once with this code; three of them run in the suite."""
     if not Path("/root/reference/glow_tts/models.py").is_file():
         pytest.skip("needs the reference checkout")
-    import torch
-    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    import subprocess
+    import sys
 
-    from larynx_amd import synthetic
-    from oracle.make_golden import build_ref_glow, build_ref_hifigan, import_reference
-    from oracle.make_onnx_fixture import GLOW, VOC
-
-    onnx_proto_utils._add_onnxscript_fn = lambda proto, custom_opsets: proto  # needs the absent `onnx` package; a no-op here
-    gm, hm, hc, _ = import_reference()
-    gsd = synthetic.make_glow_state_dict(GLOW, seed=31)
-    vsd = synthetic.make_hifigan_state_dict(VOC, seed=32)
-    lib = ffi.load_library(emu_library_path)
-
-    def worst(path, man, sd, n_split=4):
-        got = state_dict_from_onnx(path, [n for n, _ in man], n_split=n_split)
-        return float(np.abs(build_blob(man, got) - build_blob(man, sd)).max())
-
-    gen = build_ref_hifigan(hm, hc, VOC, vsd)
-    with torch.no_grad():
-        torch.onnx.export(gen, torch.randn(1, 80, 20), str(tmp_path / "v.onnx"), opset_version=opset, do_constant_folding=fold,
-                          keep_initializers_as_inputs=keep, input_names=["mel"], output_names=["audio"],
-                          dynamic_axes={"mel": {2: "frames"}, "audio": {2: "samples"}}, dynamo=False)
-    assert worst(tmp_path / "v.onnx", ffi.manifest(lib, ffi.hifigan_hparams_c(VOC)), vsd) < 2e-6
-
-    model = build_ref_glow(gm, GLOW, gsd)
-    for p in model.parameters():
-        p.requires_grad_(False)
-    for f in model.decoder.flows:
-        if hasattr(f, "weight_inv"):
-            f.weight_inv = f.weight_inv.detach()
-
-    class Wrap(torch.nn.Module):
-        def __init__(self, m):
-            super().__init__()
-            self.m = m
-
-        def forward(self, text, lengths, scales):
-            (mel, *_), _, _ = self.m(text, lengths, noise_scale=scales[0], length_scale=scales[1], g=None)
-            return mel
-
-    text = torch.randint(1, GLOW.num_symbols, (1, 17))
-    with torch.no_grad():
-        torch.onnx.export(Wrap(model), (text, torch.LongTensor([17]), torch.FloatTensor([0.667, 1.0])), str(tmp_path / "g.onnx"),
-                          opset_version=opset, do_constant_folding=fold, keep_initializers_as_inputs=keep,
-                          input_names=["input", "input_lengths", "scales"], output_names=["output"],
-                          dynamic_axes={"input": {0: "batch", 1: "phonemes"}, "input_lengths": {0: "batch"},
-                                        "output": {0: "batch", 2: "frames"}}, dynamo=False)
-    assert worst(tmp_path / "g.onnx", ffi.manifest(lib, ffi.glow_hparams_c(GLOW)), gsd, GLOW.n_split) < 2e-6
+    p = subprocess.run([sys.executable, str(Path(__file__).with_name("onnx_variants_check.py")), str(opset), str(int(fold)), str(int(keep)),
+                        str(emu_library_path), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    worst = json.loads(p.stdout.strip().splitlines()[-1])
+    assert worst["hifigan"] < 2e-6 and worst["glow"] < 2e-6, worst
