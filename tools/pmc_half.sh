@@ -8,8 +8,6 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-config3 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --precision bf16x3"
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq -o sq --output-format csv -- $BENCH > $OUT/bench_sq.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA -d $OUT/pmc_sq2 -o sq2 --output-format csv -- $BENCH > $OUT/bench_sq2.log 2>&1
-timeout 240 rocprofv3 --kernel-trace --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TA_BUSY_avr -d $OUT/pmc_tc -o tc --output-format csv -- $BENCH > $OUT/bench_tc.log 2>&1
 for f in $OUT/*/*counter_collection.csv; do python tools/pmc_reduce.py $f > ${f%.csv}_by_kernel.csv; rm -f $f; done
 rm -f $OUT/*/*_agent_info.csv
 grep -h "conv_bf16" $OUT/*/*_by_kernel.csv | cut -c1-200
-tail -3 $OUT/bench_tc.log | cut -c1-300
