@@ -42,7 +42,7 @@ sys.path.insert(0, str(REPO))
 
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, f32 MFMA = f32 vector peak
 SAMPLE_RATE = 22050
-ROUND = "r02"
+ROUND = "r03"
 
 
 def algorithmic_flop(P: int, F: float, quality: str = "high") -> float:
@@ -138,6 +138,154 @@ def config3_ids(num_symbols: int, n: int = 256, mean: float = 120.0, std: float 
     return [synthetic.synthetic_phoneme_ids(rng, int(p), num_symbols) for p in lens]
 
 
+CONFIG4_P = (19, 26, 31, 33, 64, 47, 90, 120)  # SURVEY.md §8(d) config 4 (first five = the thorsten fixture sentences)
+
+
+def config4_rows(num_symbols: int):
+    """The rows of the golden batch (tests/golden/batch8, every row pinned to the reference) when the fixture is in the
+    tree, else seeded synthetic ids of the same lengths."""
+    gp = REPO / "tests" / "golden" / "batch8" / "thorsten_medium_batch8.npz"
+    if gp.is_file():
+        z = np.load(gp)
+        rows = [np.asarray(z[f"ids{b}"], np.int64) for b in range(8)]
+        if tuple(len(r) for r in rows) == CONFIG4_P:
+            return rows, float(z["length_scale"]), "tests/golden/batch8/thorsten_medium_batch8.npz"
+    from larynx_amd import synthetic
+
+    rng = np.random.default_rng(4)
+    return [synthetic.synthetic_phoneme_ids(rng, n, num_symbols) for n in CONFIG4_P], 0.5, "seeded synthetic ids"
+
+
+def config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_dist, audio):
+    """BASELINE config 4 on this rank; returns the `config4` object (timings MAX-reduced over ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    from larynx_amd import ffi
+    from larynx_amd import hparams as HP
+    from larynx_amd import synthetic
+
+    ghp, vhp = HP.THORSTEN, HP.HIFIGAN_MEDIUM
+    g = eng.load_glow(ghp, synthetic.make_glow_state_dict(ghp, seed=1234))  # seeded: identical on every rank, = the golden's
+    v = eng.load_hifigan(vhp, synthetic.make_hifigan_state_dict(vhp, seed=1234))
+    rows, length_scale, src = config4_rows(ghp.num_symbols)
+    B, ld = len(rows), max(len(r) for r in rows)
+    lens = np.array([len(r) for r in rows], np.int32)
+    packed = np.zeros((B, ld), np.int64)
+    for b, r in enumerate(rows):
+        packed[b, : len(r)] = r
+    ids_dev = torch.from_numpy(packed).to(dev)
+    hop = vhp.hop
+    max_frames = ld * 12
+    max_samples = max_frames * hop
+    wav_f32 = [torch.empty(B * max_samples, dtype=torch.float32, device=dev) for _ in range(conc)]
+    wav_i16 = [torch.empty(B * max_samples, dtype=torch.int16, device=dev) for _ in range(conc)]
+    flags = ffi.IN_DEVICE | ffi.OUT_DEVICE
+    eng.reserve(conc + 1, g, v, max_batch=B, max_ids=ld, max_frames=max_frames)
+    K = max(4, args.steps // 2)
+
+    def call(i, slot=0):
+        fr = eng.synthesize_raw(g, v, ids_dev.data_ptr(), lens, ld, 0.667, length_scale, wav_f32[slot].data_ptr(),
+                                wav_i16[slot].data_ptr(), max_samples, seed=4000 + i, audio_settings=audio, flags=flags)
+        return fr
+
+    def run(n, threads):
+        if pool is None or threads <= 1:
+            for i in range(n):
+                call(i)
+            return
+        import queue
+
+        q = queue.SimpleQueue()
+        for i in range(n):
+            q.put(i)
+
+        def work(slot):
+            while True:
+                try:
+                    i = q.get_nowait()
+                except queue.Empty:
+                    return
+                call(i, slot)
+
+        list(pool.map(work, range(threads)))
+
+    frames = call(0)
+    run(max(2, conc), conc)  # every in-flight slot at this shape
+    eng.set_profiling(True)
+    call(0)
+    eng.profile_reset()
+    barrier()
+    for i in range(K):
+        call(i)
+    barrier()
+    prof = eng.profile()
+    eng.set_profiling(False)
+    call(0)
+    reps = max(5, min(20, int(np.ceil(1.0 / max(1e-4, min(timed(lambda: run(K, 1), 1)))))))
+    t_single = timed(lambda: run(K, 1), reps)
+    t_flight = timed(lambda: run(K, conc), reps) if conc > 1 else t_single
+    st = torch.tensor([float(np.median(t_flight)), float(np.median(t_single)), min(t_flight), max(t_flight)], dtype=torch.float64, device=red_dev)
+    if use_dist:
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    dt_f, dt_s, dt_min, dt_max = (float(x) for x in st)
+    eng.unload(g)
+    eng.unload(v)
+    F = int(frames.sum())
+    audio_s = F * hop / SAMPLE_RATE
+    flop = sum(algorithmic_flop(int(p), float(f), "medium") for p, f in zip(lens, frames))
+    wide, narrow = prof["conv_mfma.hifigan_resblock"], prof["mrf_small.hifigan_narrow_stage"]
+
+    def tf(c):
+        return c["flop"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else None
+
+    # algorithmic bytes of a narrow-stage launch: one read + one write of the stage's [C x L] plane per row
+    C0 = vhp.upsample_initial_channel
+    ups = np.cumprod(vhp.upsample_rates)
+    narrow_bytes = sum(2 * 4 * (C0 >> (i + 1)) * int(ups[i]) * F for i in range(len(ups)) if (C0 >> (i + 1)) <= 16)
+    return {
+        "workload": f"de-de thorsten GlowTTS (V=54) + hifi_gan 'medium', ONE padded batch of 8 rows per call, P = {list(map(int, lens))} "
+                    f"-> frames {list(map(int, frames))} ({F} frames = {audio_s:.2f} s audio per call; ids: {src}), length_scale "
+                    f"{length_scale}, fused entry (mi355tts_synthesize), ids and waveforms device resident, {conc} calls in flight",
+        "batch": B,
+        "frames_per_call": F,
+        "steps": K,
+        "repeats": reps,
+        "ms_per_call": 1e3 * dt_f / K,
+        "ms_per_call_min": 1e3 * dt_min / K,
+        "ms_per_call_max": 1e3 * dt_max / K,
+        "utterances_per_sec": world * K * B / dt_f,
+        "x_realtime_per_gpu": audio_s * K / dt_f,
+        "latency_ms_single_stream": 1e3 * dt_s / K,
+        "end_to_end_tflops_per_gpu": flop * K / dt_f / 1e12,
+        "algorithmic_gflop_per_call": flop / 1e9,
+        "scaling": "weak",
+        "roofline": {
+            "narrow_stages": {
+                "kernel": "mrf_small_kernel: the 16- and 8-channel stages, all three ResBlock1 chains + their average per launch "
+                          "(v_mfma_f32_16x16x4_f32 on an LDS-resident tile)",
+                "bound": "mfma",
+                "why": "fused, a stage is 252 (C = 8) / 504 (C = 16) FLOP per byte of its one read + one write — far above the ~20 FLOP/B ridge",
+                "achieved": tf(narrow), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (tf(narrow) or 0.0) / FP32_PEAK_TFLOPS,
+                "launches": narrow["launches"], "avg_launch_us": 1e3 * narrow["ms"] / max(1, narrow["launches"]),
+                "ms_per_call": narrow["ms"] / K,
+                "algorithmic_bytes_per_call": narrow_bytes,
+                "algorithmic_gbytes_per_s": narrow_bytes * K / (narrow["ms"] * 1e-3) / 1e9 if narrow["ms"] > 0 else None,
+            },
+            "wide_stages": {
+                "kernel": "pair_group_kernel (fused conv pairs, 64- and 32-channel stages)",
+                "bound": "mfma", "achieved": tf(wide), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (tf(wide) or 0.0) / FP32_PEAK_TFLOPS,
+                "launches": wide["launches"], "avg_launch_us": 1e3 * wide["ms"] / max(1, wide["launches"]),
+                "ms_per_call": wide["ms"] / K,
+            },
+            "timing": "HIP events on the launch stream around every launch, profiled single-stream pass of the same K calls",
+        },
+        "profile_ms_per_call": {k_: v_["ms"] / K for k_, v_ in prof.items()},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +310,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-half-mode", action="store_true", help="skip the secondary bf16x3 (`half` switch) leg")
     ap.add_argument("--config3-utterances", type=int, default=256)
+    ap.add_argument("--no-config4", action="store_true", help="skip BASELINE config 4 (thorsten + 'medium', one padded batch of 8)")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config5-sentences", type=int, default=210)
     ap.add_argument("--config5-threads", type=int, default=3,
@@ -538,6 +687,13 @@ def main():
         for _, g_i in voices[1:]:
             eng.unload(g_i)
 
+    # ---- BASELINE config 4: de-de thorsten GlowTTS + hifi_gan 'medium', ONE padded batch of 8 variable-length rows
+    # (P = 19 ... 120: the golden batch of tests/golden/batch8, whose every row the parity suite checks against the
+    # reference) per call, fused entry, device-resident ids and waveforms; every rank runs the same batch (weak scaling)
+    c4 = None
+    if not args.no_config4 and not args.tiny and on_gpu:
+        c4 = config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_dist, s)
+
     if rank == 0:
         audio_s = total_frames * hop / SAMPLE_RATE  # audio produced by all ranks in one K-step region
         utt_s = world * K * B / dt_flight
@@ -640,6 +796,8 @@ def main():
         }
         if c3 is not None:
             out["config3"] = c3
+        if c4 is not None:
+            out["config4"] = c4
         if c5 is not None:
             out["config5"] = c5
         if not args.no_cpu_baseline and world == 1 and on_gpu and not args.tiny:

@@ -118,8 +118,8 @@ static HifiLayout hifi_layout(const mi355tts_hifigan_hparams& h, int hop, int B,
   L.total = cv.pos;
   return L;
 }
-static bool hifi_split_out(const mi355tts_ctx* ctx, const mi355tts_hifigan_hparams& h) {
-  return !ctx->serial_branches && h.num_kernels >= 2 && h.num_kernels <= 3;
+static bool hifi_split_out(bool serial_branches, const mi355tts_hifigan_hparams& h) {
+  return !serial_branches && h.num_kernels >= 2 && h.num_kernels <= 3;
 }
 
 // The forward pass proper on worker `w` (already checked by hifigan_precheck); ends with the
@@ -172,7 +172,9 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   // same values in the same order: results do not depend on the load.
   // `serial_branches` (profiling / tests) additionally folds the average into the chains'
   // last epilogues (in-place accumulation, one output buffer).
-  const bool split_out = hifi_split_out(ctx, h);
+  // the option flags, read once: a call never mixes schedules if an option changes while it runs
+  const bool opt_serial = ctx->serial_branches.load(), opt_group = ctx->mrf_group.load(), opt_small = ctx->mrf_small.load();
+  const bool split_out = hifi_split_out(opt_serial, h);
   // grouped (default): the chains stay on ONE stream and the same-geometry launches of a step go out as
   // one grouped launch (conv_group_kernel / pair_group_kernel) — the chip is filled from one launch, with
   // no stream fork/join and independently of what else is in flight.  "mrf_group" = 0 restores the
@@ -181,9 +183,9 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   // +3 % utterances/s at 6 calls in flight with the round-2 mid-way kernels; with the final tiles the grouped
   // launch wins under load too (f32 +1.3 %, split-bf16 +5 %, same box), so the option is off by default.
   // Every form runs the same tiles with the same code: results do not depend on the load.
-  const bool busy = ctx->adaptive_schedule && ctx->active_calls.load(std::memory_order_relaxed) > 1;
-  const bool grouped = split_out && nk == 3 && ctx->mrf_group && !busy;
-  const bool concurrent = split_out && !ctx->mrf_group && !busy;
+  const bool busy = ctx->adaptive_schedule.load() && ctx->active_calls.load(std::memory_order_relaxed) > 1;
+  const bool grouped = split_out && nk == 3 && opt_group && !busy;
+  const bool concurrent = split_out && !opt_group && !busy;
   if (concurrent && !w->aux[0]) {
     for (int i = 0; i < 2; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&w->aux[i], hipStreamNonBlocking));
@@ -250,6 +252,17 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     ch = cout;
     const long long bs = (long long)ch * ldo;
     const float inv_nk = 1.0f / (float)nk;
+    if (opt_small && !opt_serial && i < (int)hm->mrf.size() && hm->mrf[i].ok) {
+      // narrow stage (C = 8 / 16): all three chains and their average in ONE launch on an LDS-resident tile.
+      // The stage-input plane (or the previous stage's chain outputs) is dead once the upsampler has read it.
+      float* dst = buf[0];
+      CHECK(run_mrf_small(ctx, w, hm->mrf[i], hm->arena, xu, dst, bs, ldo, d_frames, mul, B, Lout, voc_host_len, s));
+      cur[0] = dst;
+      ncur = 1;
+      Lin = Lout;
+      ldin = ldo;
+      continue;
+    }
     if (concurrent) {
       HIPCHECK(hipEventRecord(w->ev_fork, s));
       for (int j = 1; j < nk; ++j) HIPCHECK(hipStreamWaitEvent(w->aux[j - 1], w->ev_fork, 0));

@@ -8,10 +8,11 @@ struct ProfEvent {
   int cls;
   double flop;
 };
-enum KClass { KC_RESBLOCK = 0, KC_UPSAMPLE, KC_VOC_IO, KC_GLOW_ENC_CONV, KC_GLOW_DEC_CONV, KC_SMALL, KC_COUNT };
+enum KClass { KC_RESBLOCK = 0, KC_UPSAMPLE, KC_VOC_IO, KC_GLOW_ENC_CONV, KC_GLOW_DEC_CONV, KC_SMALL, KC_MRF_NARROW, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_mfma.hifigan_upsample",
                                             "conv_mfma.hifigan_pre_post", "conv_mfma.glow_encoder",
-                                            "conv_mfma.glow_decoder",     "elementwise"};
+                                            "conv_mfma.glow_decoder",     "elementwise",
+                                            "mrf_small.hifigan_narrow_stage"};
 
 struct Worker {
   hipStream_t stream = nullptr;
@@ -38,13 +39,16 @@ struct mi355tts_ctx {
   int next_id = 1;
   std::vector<Worker*> free_workers;
   std::vector<Worker*> all_workers;
-  bool profiling = false;
-  bool serial_branches = false;
+  // option flags: written by mi355tts_set_option / _set_profiling while calls are in flight on other threads -> atomics;
+  // a call reads each flag ONCE at its start (hifigan_run) so one call never mixes schedules
+  std::atomic<bool> profiling{false};
+  std::atomic<bool> serial_branches{false};
   // calls currently holding a worker; with "adaptive_schedule" on and more than one in flight the vocoder
   // launches the members of a grouped step one by one (and never forks its MRF chains)
   std::atomic<int> active_calls{0};
-  bool adaptive_schedule = false;
-  bool mrf_group = true;  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
+  std::atomic<bool> adaptive_schedule{false};
+  std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
+  std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;

@@ -10,7 +10,7 @@ struct ProfScope {
   ProfEvent ev;
   hipStream_t st;
   ProfScope(mi355tts_ctx* c, Worker* wk, int cls, double flop, hipStream_t stream = nullptr)
-      : ctx(c), w(wk), on(c->profiling), st(stream ? stream : wk->stream) {
+      : ctx(c), w(wk), on(c->profiling.load()), st(stream ? stream : wk->stream) {
     if (!on) return;
     if (!w->event_pool.empty()) {
       ev.a = w->event_pool.back().first;
@@ -553,6 +553,38 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   }
   if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 1, 2>), grid, dim3(512), 0, s, g);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 2, 1>), grid, dim3(512), 0, s, g);
+  return 0;
+}
+
+// ---- the one-launch MRF stage of the narrow HiFi-GAN stages (mrf_small.h)
+// x -> y = average of the three ResBlock1 chains, [B][C][ld] planes; len/len_mul as everywhere (row b is len[b]*len_mul long)
+static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const float* arena, const float* x, float* y, long long bs,
+                         int ld, const int* len, int len_mul, int B, int Lmax, int host_len, hipStream_t s) {
+  if (!ms.ok || (ld % 4) || x == y || Lmax <= 0) return fail(MI355TTS_ERR_INVALID, "internal: MRF stage not covered by the fused kernel");
+  MrfArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.y = y;
+  a.bs = bs;
+  a.ld = ld;
+  a.len = (B == 1 && host_len >= 0) ? nullptr : len;
+  a.len_mul = len_mul;
+  a.len_const = host_len * len_mul;
+  a.w = arena + ms.w_off;
+  a.bias = arena + ms.b_off;
+  std::memcpy(a.woff, ms.woff, sizeof(a.woff));
+  std::memcpy(a.dil, ms.dil, sizeof(a.dil));
+  a.nsteps = ms.nsteps;
+  a.slope = 0.1f;
+  static const int t_env = [] { const char* e = std::getenv("MI355TTS_MRF_T"); return e ? std::atoi(e) : 0; }();
+  // tile: 256 columns at C = 16 (77 KB of LDS, two workgroups per CU); 512 at C = 8 unless that leaves CUs without a tile
+  int T = ms.C == 16 ? 256 : ((long long)((Lmax + 511) / 512) * B >= 512 ? 512 : 256);
+  if (t_env == 256 || (t_env == 512 && ms.C == 8)) T = t_env;
+  const dim3 grid((Lmax + T - 1) / T, 1, B);
+  ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
+  if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  else if (T == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 512, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   return 0;
 }
 

@@ -151,6 +151,15 @@ struct HifiResConv {
   DevConv c1, c2;
   int dil;
 };
+// A narrow stage (C = 8 / 16) packed for the one-launch MRF kernel (mrf_small.h)
+struct MrfStage {
+  bool ok = false;
+  int C = 0, nsteps = 0;
+  size_t w_off = 0, b_off = 0;  // offsets (floats) into the model arena
+  int woff[3][MRF_MAX_STEPS][2] = {};
+  int dil[3][MRF_MAX_STEPS] = {};
+  double mac_per_col = 0;  // algorithmic MACs per output column (all 18 convs)
+};
 struct HifiModel {
   mi355tts_hifigan_hparams hp;
   float* arena = nullptr;
@@ -160,6 +169,7 @@ struct HifiModel {
   std::vector<DevConv> ups;
   // [stage][kernel][dilation index]
   std::vector<std::vector<std::vector<HifiResConv>>> rb;
+  std::vector<MrfStage> mrf;  // per stage
   int hop = 1;
   // denoiser bias spectrum |STFT(generator(zeros))|[:, 0] (larynx/hifi_gan.py:181-203), built on first use
   std::mutex bias_mu;

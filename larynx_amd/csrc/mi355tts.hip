@@ -28,6 +28,7 @@
 #include "resblock_pair.h"
 #include "conv_bf16.h"
 #include "resblock_pair_bf16.h"
+#include "mrf_small.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -383,6 +384,23 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     hm->ups.push_back(add_conv(ab, w, b, cout, cin, ku, ROWS_UPSAMPLE, u));
     ch = cout;
     hm->rb[i].resize(h.num_kernels);
+    // narrow stages additionally get the packing of the one-launch MRF kernel (mrf_small.h): ResBlock1 chains
+    // with taps (3, 7, 11), <= 3 dilation steps and a receptive half-width within the staged halo
+    MrfStage ms;
+    std::vector<float> mrf_w, mrf_b;
+    ms.ok = h.resblock_type == 1 && h.num_kernels == 3 && (ch == 8 || ch == 16) && h.num_dilations <= MRF_MAX_STEPS &&
+            h.resblock_kernel_sizes[0] == 3 && h.resblock_kernel_sizes[1] == 7 && h.resblock_kernel_sizes[2] == 11;
+    for (int j = 0; ms.ok && j < h.num_kernels; ++j) {
+      int need = 0;
+      for (int d = 0; d < h.num_dilations; ++d) {
+        if (h.resblock_dilations[j][d] < 1) ms.ok = false;
+        need += (h.resblock_kernel_sizes[j] - 1) / 2 * (h.resblock_dilations[j][d] + 1);
+      }
+      if (need > MRF_HALO) ms.ok = false;
+    }
+    ms.C = ch;
+    ms.nsteps = h.num_dilations;
+    if (ms.ok) mrf_b.assign((size_t)3 * MRF_MAX_STEPS * 2 * 16, 0.f);
     for (int j = 0; j < h.num_kernels; ++j) {
       const int n = i * h.num_kernels + j;
       const int k = h.resblock_kernel_sizes[j];
@@ -399,6 +417,19 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
           rc.c2 = add_conv(ab, w2, b2, ch, ch, k, ROWS_PLAIN);
           add16(rc.c1, w1, ch, k);
           add16(rc.c2, w2, ch, k);
+          if (ms.ok) {
+            const float* ws[2] = {w1, w2};
+            const float* bs[2] = {b1, b2};
+            ms.dil[j][d] = rc.dil;
+            for (int cv = 0; cv < 2; ++cv) {
+              const float* wsrc = ws[cv];
+              std::vector<float> pk = pack_mrf_conv(ch, k, [&](int co, int ci, int kk) { return wsrc[((size_t)co * ch + ci) * k + kk]; });
+              ms.woff[j][d][cv] = (int)mrf_w.size();
+              mrf_w.insert(mrf_w.end(), pk.begin(), pk.end());
+              std::memcpy(&mrf_b[(((size_t)j * MRF_MAX_STEPS + d) * 2 + cv) * 16], bs[cv], sizeof(float) * ch);
+            }
+            ms.mac_per_col += 2.0 * ch * ch * k;
+          }
         } else {
           TAKE(w1, rb + ".convs." + std::to_string(d) + ".weight", (int64_t)ch * ch * k);
           TAKE(b1, rb + ".convs." + std::to_string(d) + ".bias", ch);
@@ -408,6 +439,11 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
         hm->rb[i][j].push_back(rc);
       }
     }
+    if (ms.ok) {
+      ms.w_off = ab.add(mrf_w);
+      ms.b_off = ab.add(mrf_b);
+    }
+    hm->mrf.push_back(ms);
   }
   {
     TAKE(w, std::string("conv_post.weight"), (int64_t)ch * 7);
@@ -946,7 +982,7 @@ extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout
   a.out_const = L;
   a.in_slope = 0.1f;
   if (const char* ab = std::getenv("MI355TTS_BENCH_ABLATE")) a.ablate = std::atoi(ab);
-  const bool prof = ctx->profiling;
+  const bool prof = ctx->profiling.load();
   ctx->profiling = false;
   g_pin_tile = tile_shape;
   int rc = 0;
@@ -982,6 +1018,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (std::strcmp(name, "adaptive_schedule") == 0) {
     ctx->adaptive_schedule = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "mrf_small") == 0) {
+    ctx->mrf_small = value != 0;
     return 0;
   }
   if (std::strcmp(name, "mrf_group") == 0) {

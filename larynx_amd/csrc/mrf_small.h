@@ -1,0 +1,285 @@
+// A whole multi-receptive-field stage of HiFi-GAN in ONE launch, for the narrow stages (C = 8 / 16 channels):
+//
+//   y = ( rb_{K0}(x) + rb_{K1}(x) + rb_{K2}(x) ) / 3                          hifi_gan/models.py:191-197
+//   rb_K(x): for d in dilations:  x = x + conv2_{K,1}( lrelu( conv1_{K,d}( lrelu(x) ) ) )      :91-98
+//
+// These stages ('medium': 16 and 8 channels at 128 / 256 samples per mel frame) hold a third of the vocoder's
+// FLOPs but are far too narrow for the 32-row / 64-channel tiles of conv_mfma.h (4x the rows and up to 8x the
+// K-depth of MFMA work would be zeros), and un-fused they move 18 x 2 planes through the caches per stage at
+// 6 FLOP/B.  Here one workgroup owns T output columns of one batch row and runs all 18 convs on an LDS-resident
+// tile: the input is staged once with 64 columns of halo on either side (the three chains need 12 / 36 / 60),
+// every intermediate stays in LDS / registers, the average of the three chains is formed in registers, and one
+// [C x T] tile is written.  HBM/cache traffic per stage = one read + one write of the plane (+ 2 x 64 / T halo).
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact f32, bit-equal to an fmaf chain) — M = 16 output channels (all of
+// them; C = 8 uses half the rows), N = 16 time columns, K-dim = 4 input channels of one tap.  A = weights,
+// pre-packed per (tap, channel quad) as one dword per lane and streamed from L2; B = activations straight out of
+// LDS, one conflict-free ds_read_b32 per MFMA (row stride = 16 mod 32 floats).  The leaky-ReLU is applied when a
+// value is WRITTEN to LDS (once per element), the raw residual stream lives in registers in the C/D layout
+// (the same lane owns the same (channel, column) positions in every conv of a chain).
+//
+// A conv only computes the columns later convs still need (the halo shrinks by (K-1)/2*d per conv); the
+// 16-column blocks of the tile are dealt to the waves so that every wave always owns its share of the core
+// blocks and the halo blocks nearest to the core first — the active set of a wave is a prefix of its slots and
+// the MFMA loop is instantiated per slot count (no predication inside the loop).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_mfma.h"
+
+namespace mi355tts {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int MRF_HALO = 64;      // staged columns on either side of the tile (>= the deepest chain's receptive half-width)
+constexpr int MRF_MAX_STEPS = 3;  // dilation steps per chain
+
+struct MrfArgs {
+  const float* x;  // stage input [B][C][ld] (the upsampler's output)
+  float* y;        // stage output [B][C][ld]: the MRF average
+  long long bs;
+  int ld;
+  const int* len;  // valid length of row b = len ? len[b] * len_mul : len_const
+  int len_mul;
+  int len_const;
+  const float* w;     // packed A fragments, see pack_mrf_conv (weights_pack.h)
+  const float* bias;  // [chain][step][conv][16], zero padded
+  int woff[3][MRF_MAX_STEPS][2];  // float offset of each conv's fragments in w
+  int dil[3][MRF_MAX_STEPS];      // conv1 dilation of each step (conv2 has dilation 1)
+  int nsteps;
+  float slope;
+};
+
+// acc[s] += conv taps over one staged source for the wave's first NB slots.
+//   wp   : this conv's fragments + lane          ([tap][C/4][64] floats)
+//   src  : LDS source ([C][W], lrelu already applied)
+//   boff : per slot, (lane >> 4) * W + 16 * block + (lane & 15)  (the B element of tap offset 0, channel quad 0)
+//   t0   : tap 0's column offset (-pad);  taps are `dil` columns apart
+template <int K, int C, int W, int NB, int NS>
+__device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], const float* __restrict__ wp, const float* __restrict__ src,
+                                              const int (&boff)[NS], const int t0, const int dil) {
+  constexpr int CQ = C / 4;
+  float an[CQ];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q) an[q] = wp[q * 64];
+#pragma unroll
+  for (int tap = 0; tap < K; ++tap) {
+    float ac[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) ac[q] = an[q];
+    if (tap + 1 < K) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) an[q] = wp[((tap + 1) * CQ + q) * 64];
+    }
+    const float* st = src + t0 + tap * dil;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q)
+#pragma unroll
+      for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q], st[boff[s] + q * 4 * W], acc[s], 0, 0, 0);
+  }
+}
+
+template <int C, int T, int NW, int K0, int K1, int K2>
+struct MrfGeom {
+  static constexpr int W = T + 2 * MRF_HALO + 16;  // LDS row stride: = 16 (mod 32) floats -> B reads of 4 rows x 16 columns hit 64 distinct banks
+  static constexpr int NCOL = T + 2 * MRF_HALO;    // staged columns
+  static constexpr int CORE = T / 16 / NW;         // core slots per wave
+  static constexpr int HS = (2 * MRF_HALO / 16 + NW - 1) / NW;  // halo slots per wave
+  static constexpr int NS = CORE + HS;
+  // + slack: edge blocks of a conv read up to (K-1)/2*d columns past the staged row (values only garbage columns use)
+  static constexpr int LDS_FLOATS = 3 * C * W + 64;
+  static_assert(T % (16 * NW) == 0 && W % 32 == 16 && HS >= 1 && HS <= 2, "tile geometry");
+  static_assert(C == 8 || C == 16, "one 16-row MFMA block of output channels");
+};
+
+template <int C, int T, int NW, int K0, int K1, int K2>
+__global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
+  using G = MrfGeom<C, T, NW, K0, K1, K2>;
+  constexpr int W = G::W, CORE = G::CORE, HS = G::HS, NS = G::NS;
+  constexpr int NT = 64 * NW;
+  __shared__ float lds[G::LDS_FLOATS];
+  float* const X0 = lds;           // raw stage input (all three chains start from it)
+  float* const XL = lds + C * W;   // lrelu(current x of the running chain): conv1's operand
+  float* const TB = lds + 2 * C * W;  // lrelu(conv1 + bias): conv2's operand
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int b = blockIdx.z;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
+  const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
+  const int j0 = tile_x * T;
+  if (j0 >= L) return;
+  const int gx0 = j0 - MRF_HALO;  // global column of LDS column 0
+  const float slope = a.slope;
+  const float* xb = a.x + (long long)b * a.bs;
+
+  // ---- stage the input tile: X0 = x, XL = lrelu(x), zero outside the sequence (16-byte loads, branch-free)
+  {
+    constexpr int F4 = G::NCOL / 4;
+    constexpr int NF4 = C * F4;
+    constexpr int NE = (NF4 + NT - 1) / NT;
+    const int ld_last4 = a.ld - 4;
+    float4 pre[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      pre[i] = *reinterpret_cast<const float4*>(xb + (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      float4 v = pre[i];
+      v.x = (c0 >= 0 && c0 < L) ? v.x : 0.f;
+      v.y = (c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+      v.z = (c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+      v.w = (c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+      if (e < NF4) {
+        *reinterpret_cast<float4*>(X0 + row * W + 4 * f) = v;
+        v.x = v.x > 0.f ? v.x : v.x * slope;
+        v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope;
+        v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
+      }
+    }
+  }
+
+  // ---- this wave's slots: core blocks first, then its halo blocks, nearest to the core first
+  // halo entry e = wave + NW*h: even -> left block 3 - e/2, odd -> right block 4 + T/16 + e/2
+  const int colq = lane & 15, rq = lane >> 4;
+  int blk[NS];
+#pragma unroll
+  for (int s = 0; s < CORE; ++s) blk[s] = MRF_HALO / 16 + wave + NW * s;
+#pragma unroll
+  for (int h = 0; h < HS; ++h) {
+    const int e = wave + NW * h;
+    blk[CORE + h] = (e & 1) ? (MRF_HALO / 16 + T / 16 + (e >> 1)) : (MRF_HALO / 16 - 1 - (e >> 1));
+  }
+  int boff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) boff[s] = rq * W + 16 * blk[s] + colq;
+  // positions this lane owns in the C/D layout: rows 4*rq + r (r = 0..3), column 16*blk[s] + colq
+  const int row0 = 4 * rq;
+  const bool rows_ok = row0 < C;  // C = 8: the upper half of the MFMA block is padding
+  bool inside[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int g = gx0 + 16 * blk[s] + colq;
+    inside[s] = g >= 0 && g < L;
+  }
+
+  floatx4 sum[CORE];
+  floatx4 xres[NS];
+  floatx4 acc[NS];
+
+  auto run_chain = [&](auto kc, const int chain) {
+    constexpr int K = decltype(kc)::value;
+    constexpr int P2 = (K - 1) / 2;
+    // remaining halo after each conv of this chain (what later convs still need on either side)
+    int need = 0;
+    for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.dil[chain][s] + 1);
+    if (chain > 0) {
+      // chain start: XL = lrelu(X0).  (No barrier needed first: the previous chain's conv1s — XL's only readers —
+      // all ended on a barrier, and its last conv2 reads TB only.)
+      for (int e = tid; e < C * (G::NCOL / 4); e += NT) {
+        const int row = e / (G::NCOL / 4), f = e - row * (G::NCOL / 4);
+        float4 v = *reinterpret_cast<const float4*>(X0 + row * W + 4 * f);
+        v.x = v.x > 0.f ? v.x : v.x * slope;
+        v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope;
+        v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
+      }
+    }
+    __syncthreads();
+    // residual stream of the owned positions
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[s][r] = rows_ok ? X0[(row0 + r) * W + 16 * blk[s] + colq] : 0.f;
+
+    for (int step = 0; step < a.nsteps; ++step) {
+      const int dil = a.dil[chain][step];
+      const bool last = step == a.nsteps - 1;
+#pragma unroll
+      for (int cv = 0; cv < 2; ++cv) {
+        const int d = cv == 0 ? dil : 1;
+        need -= P2 * d;  // halo the LATER convs still need = half-width of this conv's output range beyond the core
+        // halo slots of this wave inside the range: entries e < 2 * ceil(need / 16)
+        const int n_act = 2 * ((need + 15) >> 4);
+        int nh = 0;
+#pragma unroll
+        for (int h = 0; h < HS; ++h) nh += (wave + NW * h) < n_act ? 1 : 0;
+        const float* wp = a.w + a.woff[chain][step][cv] + lane;
+        const float* src = cv == 0 ? XL : TB;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // wave-uniform slot count -> one instantiation of the MFMA loop per count
+        if (HS >= 2 && nh >= 2) mrf_conv_taps<K, C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, wp, src, boff, -P2 * d, d);
+        else if (nh >= 1) mrf_conv_taps<K, C, W, CORE + 1, NS>(acc, wp, src, boff, -P2 * d, d);
+        else mrf_conv_taps<K, C, W, CORE, NS>(acc, wp, src, boff, -P2 * d, d);
+        const int nb = CORE + nh;
+        float bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[r] = a.bias[((chain * MRF_MAX_STEPS + step) * 2 + cv) * 16 + row0 + r];
+        if (cv == 0) {
+          // TB = lrelu(conv1 + bias), zero outside the sequence (conv2's zero padding)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (s < nb && rows_ok) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float v = acc[s][r] + bb[r];
+                v = v > 0.f ? v : v * slope;
+                TB[(row0 + r) * W + 16 * blk[s] + colq] = inside[s] ? v : 0.f;
+              }
+            }
+          }
+        } else {
+          // x = x + conv2 + bias; XL = lrelu(x) for the next step
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (s < nb) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = inside[s] ? (acc[s][r] + bb[r]) + xres[s][r] : 0.f;
+                xres[s][r] = v;
+                if (!last && rows_ok) XL[(row0 + r) * W + 16 * blk[s] + colq] = v > 0.f ? v : v * slope;
+              }
+            }
+          }
+        }
+        if (!(last && cv == 1)) __syncthreads();
+      }
+    }
+    // the MRF sum, in the reference's order (xs = rb0; xs += rb1; xs += rb2)
+#pragma unroll
+    for (int s = 0; s < CORE; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum[s][r] = chain == 0 ? xres[s][r] : sum[s][r] + xres[s][r];
+  };
+  run_chain(std::integral_constant<int, K0>{}, 0);
+  run_chain(std::integral_constant<int, K1>{}, 1);
+  run_chain(std::integral_constant<int, K2>{}, 2);
+
+  // ---- y = sum / 3
+  if (rows_ok) {
+    float* yb = a.y + (long long)b * a.bs;
+#pragma unroll
+    for (int s = 0; s < CORE; ++s) {
+      const int g = gx0 + 16 * blk[s] + colq;
+      if (g < L) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yb[(long long)(row0 + r) * a.ld + g] = sum[s][r] / 3.0f;
+      }
+    }
+  }
+}
+
+}  // namespace mi355tts

@@ -105,4 +105,21 @@ inline PackedConv16 pack_conv_bf16(int rows, int m_align, int Cin, int K, WGet w
   return p;
 }
 
+// ---- A fragments for mrf_small.h (v_mfma_f32_16x16x4_f32) ---------------------------------------
+// One conv w[C][C][K] with C <= 16 as [tap][C/4][64 lanes]: lane l of (tap, channel quad q) holds
+// W[co = l & 15][ci = 4q + (l >> 4)][tap] — the A operand A[i = l & 15][k = l >> 4] of one MFMA — and
+// zero for the padding rows co >= C.  No channel padding: the K-dim is exactly C x taps deep.
+template <typename WGet>
+inline std::vector<float> pack_mrf_conv(int C, int K, WGet wget) {
+  const int CQ = C / 4;
+  std::vector<float> p((size_t)K * CQ * 64, 0.f);
+  for (int k = 0; k < K; ++k)
+    for (int q = 0; q < CQ; ++q)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = lane & 15, ci = 4 * q + (lane >> 4);
+        if (co < C) p[((size_t)k * CQ + q) * 64 + lane] = wget(co, ci, k);
+      }
+  return p;
+}
+
 }  // namespace mi355tts

@@ -222,6 +222,15 @@ TINY_HIFIGAN_PAIR = HifiGanHParams(
 )
 
 
+# stages of 16 and 8 channels with the shipped (3, 7, 11) x (1, 3, 5) ResBlock1 chains: the one-launch MRF kernel (mrf_small.h)
+TINY_HIFIGAN_NARROW = HifiGanHParams(
+    upsample_rates=(2, 2),
+    upsample_kernel_sizes=(4, 4),
+    upsample_initial_channel=32,
+    num_mels=16,
+)
+
+
 def load_config_json(path: typing.Union[str, Path]) -> typing.Dict[str, typing.Any]:
     with open(path, "r", encoding="utf-8") as f:
         return json.load(f)
