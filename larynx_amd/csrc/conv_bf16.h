@@ -361,7 +361,13 @@ template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_bf16_kernel(const ConvArgs a) {
   __shared__ uint4 xs[conv_bf16_lds_units<NB, WN, HALO>()];
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
+  int gx = gridDim.x;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (conv_mfma.h, row_tiles)
+    gx = row_tiles(conv_n_len<K, EPI_LINEAR>(a, blockIdx.z), 32 * NB * WN);
+    if (lin >= gx * (int)gridDim.y) return;
+  }
+  xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
   conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS, KS>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
@@ -375,20 +381,25 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (NB == 4 && KS == 1) ? BF16_OCC 
   __shared__ uint4 xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
+  const bool ragged = gridDim.z > 1;  // a row deals only its own tiles (conv_mfma.h, row_tiles)
+  constexpr int T_T = 32 * NB * WN;
   int tx, ty;
   if (lin < g.off[1]) {
-    if (lin >= g.gx[0] * g.gy[0]) return;
-    xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), T_T) : g.gx[0];
+    if (lin >= gx * g.gy[0]) return;
+    xcd_tile_lin(lin, gx, g.gy[0], tx, ty);
     conv_bf16_tile<K0, MB, NB, WM, WN, H0, TERMS, KS>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
-    if (l >= g.gx[1] * g.gy[1]) return;
-    xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K1, EPI_LINEAR>(g.c[1], b), T_T) : g.gx[1];
+    if (l >= gx * g.gy[1]) return;
+    xcd_tile_lin(l, gx, g.gy[1], tx, ty);
     conv_bf16_tile<K1, MB, NB, WM, WN, H1, TERMS, KS>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
-    if (l >= g.gx[2] * g.gy[2]) return;
-    xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K2, EPI_LINEAR>(g.c[2], b), T_T) : g.gx[2];
+    if (l >= gx * g.gy[2]) return;
+    xcd_tile_lin(l, gx, g.gy[2], tx, ty);
     conv_bf16_tile<K2, MB, NB, WM, WN, H2, TERMS, KS>(g.c[2], tx, ty, b, xs);
   }
 }

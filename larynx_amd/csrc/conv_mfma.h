@@ -136,6 +136,25 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty, int r
   xcd_tile_lin(blockIdx.x + blockIdx.y * gx, gx, gy, tx, ty, rows_major);
 }
 
+// Ragged batches (gridDim.z > 1 rows of different lengths): the grid is sized for the longest row, and dealing
+// contiguous runs of the GRID's tiles to the XCDs would hand a short row's few real tiles to XCD 0 (and 1) alone —
+// over a batch of 8 rows with lengths 0.14 ... 1.0 of the longest, XCD 0 gets 8 shares of work and XCD 7 one
+// (measured on BASELINE config 4: the 32-channel fused pair launches ran at 0.24 of peak against 0.59 at batch 1).
+// So a row deals only ITS OWN tiles: the first gx_row * gy workgroups of the row's grid slice take them (spread
+// evenly over the XCDs by the dispatcher's round-robin), the rest exit.
+__device__ __forceinline__ int row_tiles(int n_len, int tile) { return (n_len + tile - 1) / tile; }
+
+// extent of the implicit GEMM's N axis for batch row b (conv_tile derives the same value)
+template <int K, int EPI>
+__device__ __forceinline__ int conv_n_len(const ConvArgs& a, int b) {
+  if constexpr (EPI == EPI_UPSAMPLE) {
+    const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
+    return Lin > 0 ? Lin + (K - 1) : 0;
+  } else {
+    return a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
+  }
+}
+
 // LDS floats one workgroup of a tile shape needs (staging double buffer, reused by the k-group reduction)
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, int WM = 1>
 constexpr int conv_lds_floats() {
@@ -774,7 +793,13 @@ template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI, in
 __global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && ((NB == 1 && MB == 2) || (MB == 1 && NB == 2 && KS == 4))) || WM == 4) ? 4 : 1) void conv_mfma_kernel(const ConvArgs a) {
   __shared__ float xs[conv_lds_floats<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>()];
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y, a.rows_major);
+  int gx = gridDim.x;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (see row_tiles)
+    gx = row_tiles(conv_n_len<K, EPI>(a, blockIdx.z), WN * NB * 32);
+    if (lin >= gx * (int)gridDim.y) return;
+  }
+  xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
   conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
@@ -801,20 +826,25 @@ __global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4
   __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
+  const bool ragged = gridDim.z > 1;  // rows of different lengths: a row deals only its own tiles (see row_tiles)
+  constexpr int T_T = WN * NB * 32;
   int tx, ty;
   if (lin < g.off[1]) {
-    if (lin >= g.gx[0] * g.gy[0]) return;
-    xcd_tile_lin(lin, g.gx[0], g.gy[0], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), T_T) : g.gx[0];
+    if (lin >= gx * g.gy[0]) return;
+    xcd_tile_lin(lin, gx, g.gy[0], tx, ty);
     conv_tile<K0, CI_C, MB, NB, WN, KS, H0, EPI_LINEAR, WM>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
-    if (l >= g.gx[1] * g.gy[1]) return;
-    xcd_tile_lin(l, g.gx[1], g.gy[1], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K1, EPI_LINEAR>(g.c[1], b), T_T) : g.gx[1];
+    if (l >= gx * g.gy[1]) return;
+    xcd_tile_lin(l, gx, g.gy[1], tx, ty);
     conv_tile<K1, CI_C, MB, NB, WN, KS, H1, EPI_LINEAR, WM>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
-    if (l >= g.gx[2] * g.gy[2]) return;
-    xcd_tile_lin(l, g.gx[2], g.gy[2], tx, ty);
+    const int gx = ragged ? row_tiles(conv_n_len<K2, EPI_LINEAR>(g.c[2], b), T_T) : g.gx[2];
+    if (l >= gx * g.gy[2]) return;
+    xcd_tile_lin(l, gx, g.gy[2], tx, ty);
     conv_tile<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR, WM>(g.c[2], tx, ty, b, xs);
   }
 }

@@ -107,8 +107,10 @@ __global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
   const int wave = tid >> 6;
   const int b = blockIdx.z;
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
+  const int gx = gridDim.z > 1 ? row_tiles(L, T) : (int)gridDim.x;  // ragged batch: this row's own tiles only (conv_mfma.h)
+  if ((int)blockIdx.x >= gx) return;
+  xcd_tile_lin(blockIdx.x, gx, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
   const int j0 = tile_x * T;
   if (j0 >= L) return;
   const int gx0 = j0 - MRF_HALO;  // global column of LDS column 0

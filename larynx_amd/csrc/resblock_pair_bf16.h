@@ -279,7 +279,12 @@ template <int K, int WM, int WN, int NB, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 4) ? 4 : 1) void pair_bf16_kernel(const PairArgs a) {
   __shared__ uint4 xs[PairBf16Geom<K, WM, WN, NB>::UNITS];
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
+  int gx = gridDim.x;
+  if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (conv_mfma.h, row_tiles)
+    gx = row_tiles(a.len ? a.len[blockIdx.z] * a.len_mul : a.len_const, PairBf16Geom<K, WM, WN, NB>::T1 - (K - 1));
+    if ((int)blockIdx.x >= gx) return;
+  }
+  xcd_tile_lin(blockIdx.x, gx, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
   pair_bf16_tile<K, WM, WN, NB, TERMS>(a, tile_x, blockIdx.z, xs);
 }
 
@@ -290,20 +295,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 4) ? 4 : 1) void pa
   __shared__ uint4 xs[U0 > U1 ? (U0 > U2 ? U0 : U2) : (U1 > U2 ? U1 : U2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
+  // ragged batch: a row deals only its own tiles (conv_mfma.h, row_tiles)
+  auto tiles = [&](const PairArgs& p, int gx_grid, int t2) { return gridDim.z > 1 ? row_tiles(p.len ? p.len[b] * p.len_mul : p.len_const, t2) : gx_grid; };
+  constexpr int T1 = PairBf16Geom<K0, WM, WN, NB>::T1;
   int tx, ty;
   if (lin < g.off[1]) {
-    if (lin >= g.gx[0]) return;
-    xcd_tile_lin(lin, g.gx[0], 1, tx, ty);
+    const int gx = tiles(g.p[0], g.gx[0], T1 - (K0 - 1));
+    if (lin >= gx) return;
+    xcd_tile_lin(lin, gx, 1, tx, ty);
     pair_bf16_tile<K0, WM, WN, NB, TERMS>(g.p[0], tx, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
-    if (l >= g.gx[1]) return;
-    xcd_tile_lin(l, g.gx[1], 1, tx, ty);
+    const int gx = tiles(g.p[1], g.gx[1], T1 - (K1 - 1));
+    if (l >= gx) return;
+    xcd_tile_lin(l, gx, 1, tx, ty);
     pair_bf16_tile<K1, WM, WN, NB, TERMS>(g.p[1], tx, b, xs);
   } else {
     const int l = lin - g.off[2];
-    if (l >= g.gx[2]) return;
-    xcd_tile_lin(l, g.gx[2], 1, tx, ty);
+    const int gx = tiles(g.p[2], g.gx[2], T1 - (K2 - 1));
+    if (l >= gx) return;
+    xcd_tile_lin(l, gx, 1, tx, ty);
     pair_bf16_tile<K2, WM, WN, NB, TERMS>(g.p[2], tx, b, xs);
   }
 }
