@@ -223,11 +223,12 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     ConvArgs a = base_args(mel->voc, (long long)mel->M * mel->ld, mel->ld, d_frames, 1, cur[0], (long long)C0 * Fp, Fp, d_frames, 1, 1, 3);
     CHECK(launch_conv(ctx, w, hm->pre, a, EPI_LINEAR, B, F, KC_VOC_IO, nullptr, 1024, voc_host_len));
   }
+  float cur_div = 1.0f;  // the stage input is (cur[0] + ... + cur[ncur-1]) / cur_div
   auto set_inputs = [&](ConvArgs& a) {
     if (ncur > 1) {
       a.x2 = cur[1];
       a.x3 = ncur > 2 ? cur[2] : nullptr;
-      a.in_div = (float)ncur;
+      a.in_div = cur_div;
     }
   };
   int mul = 1;
@@ -253,12 +254,14 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     const long long bs = (long long)ch * ldo;
     const float inv_nk = 1.0f / (float)nk;
     if (opt_small && !opt_serial && i < (int)hm->mrf.size() && hm->mrf[i].ok) {
-      // narrow stage (C = 8 / 16): all three chains and their average in ONE launch on an LDS-resident tile.
-      // The stage-input plane (or the previous stage's chain outputs) is dead once the upsampler has read it.
-      float* dst = buf[0];
-      CHECK(run_mrf_small(ctx, w, hm->mrf[i], hm->arena, xu, dst, bs, ldo, d_frames, mul, B, Lout, voc_host_len, s));
-      cur[0] = dst;
-      ncur = 1;
+      // narrow stage (C = 8 / 16): the three chains in ONE launch on LDS-resident tiles, written as two sums
+      // (k = 3 + k = 7, and k = 11) that the consumer adds and divides by nk on load.  The stage-input plane and
+      // the previous stage's chain outputs are dead once the upsampler has read them.
+      CHECK(run_mrf_small(ctx, w, hm->mrf[i], hm->arena, xu, buf[0], buf[2], bs, ldo, d_frames, mul, B, Lout, voc_host_len, s));
+      cur[0] = buf[0];
+      cur[1] = buf[2];
+      ncur = 2;
+      cur_div = (float)nk;
       Lin = Lout;
       ldin = ldo;
       continue;
@@ -398,12 +401,14 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     if (split_out) {
       for (int j = 0; j < nk; ++j) cur[j] = outs[j];
       ncur = nk;
+      cur_div = (float)nk;
       flip ^= 1;
     } else {
       // serial: buf[5] holds the averaged sum; rotate it with the stage-input buffer
       std::swap(buf[5], buf[0]);
       cur[0] = buf[0];
       ncur = 1;
+      cur_div = 1.0f;
     }
     Lin = Lout;
     ldin = ldo;

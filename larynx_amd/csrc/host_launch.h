@@ -557,14 +557,17 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
 }
 
 // ---- the one-launch MRF stage of the narrow HiFi-GAN stages (mrf_small.h)
-// x -> y = average of the three ResBlock1 chains, [B][C][ld] planes; len/len_mul as everywhere (row b is len[b]*len_mul long)
-static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const float* arena, const float* x, float* y, long long bs,
-                         int ld, const int* len, int len_mul, int B, int Lmax, int host_len, hipStream_t s) {
-  if (!ms.ok || (ld % 4) || x == y || Lmax <= 0) return fail(MI355TTS_ERR_INVALID, "internal: MRF stage not covered by the fused kernel");
+// x -> y = rb_3(x) + rb_7(x), y2 = rb_11(x) ([B][C][ld] planes; the consumer forms (y + y2) / 3 on load);
+// len/len_mul as everywhere (row b is len[b]*len_mul long)
+static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const float* arena, const float* x, float* y, float* y2,
+                         long long bs, int ld, const int* len, int len_mul, int B, int Lmax, int host_len, hipStream_t s) {
+  if (!ms.ok || (ld % 4) || x == y || x == y2 || y == y2 || Lmax <= 0)
+    return fail(MI355TTS_ERR_INVALID, "internal: MRF stage not covered by the fused kernel");
   MrfArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x;
   a.y = y;
+  a.y2 = y2;
   a.bs = bs;
   a.ld = ld;
   a.len = (B == 1 && host_len >= 0) ? nullptr : len;
@@ -572,16 +575,25 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   a.len_const = host_len * len_mul;
   a.w = arena + ms.w_off;
   a.bias = arena + ms.b_off;
-  std::memcpy(a.woff, ms.woff, sizeof(a.woff));
-  std::memcpy(a.dil, ms.dil, sizeof(a.dil));
+  a.tab = reinterpret_cast<const int*>(arena + ms.t_off);
   a.nsteps = ms.nsteps;
   a.slope = 0.1f;
   static const int t_env = [] { const char* e = std::getenv("MI355TTS_MRF_T"); return e ? std::atoi(e) : 0; }();
   // tile: 256 columns at C = 16 (77 KB of LDS, two workgroups per CU); 512 at C = 8 unless that leaves CUs without a tile
   int T = ms.C == 16 ? 256 : ((long long)((Lmax + 511) / 512) * B >= 512 ? 512 : 256);
   if (t_env == 256 || (t_env == 512 && ms.C == 8)) T = t_env;
-  const dim3 grid((Lmax + T - 1) / T, 1, B);
+  const dim3 grid((Lmax + T - 1) / T, 2, B);
   ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
+  static const int nw_env = [] { const char* e = std::getenv("MI355TTS_MRF_NW"); return e ? std::atoi(e) : 0; }();
+  if (nw_env == 8) {  // experiment: 8 waves per workgroup
+    if (ms.C == 16 && t_env == 512) {
+      const dim3 g2((Lmax + 511) / 512, 2, B);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 512, 8, 3, 7, 11>), g2, dim3(512), 0, s, a);
+    } else if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 256, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
+    else if (T == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 512, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 256, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
+    return 0;
+  }
   if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   else if (T == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 512, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);

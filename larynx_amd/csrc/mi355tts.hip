@@ -442,6 +442,15 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     if (ms.ok) {
       ms.w_off = ab.add(mrf_w);
       ms.b_off = ab.add(mrf_b);
+      int tab[MRF_TAB_INTS] = {};
+      for (int j = 0; j < 3; ++j)
+        for (int d = 0; d < MRF_MAX_STEPS; ++d) {
+          tab[(j * MRF_MAX_STEPS + d) * 2 + 0] = ms.woff[j][d][0];
+          tab[(j * MRF_MAX_STEPS + d) * 2 + 1] = ms.woff[j][d][1];
+          tab[MRF_TAB_DIL + j * MRF_MAX_STEPS + d] = ms.dil[j][d];
+        }
+      static_assert(sizeof(int) == sizeof(float), "the table rides in the float arena");
+      ms.t_off = ab.add(reinterpret_cast<const float*>(tab), MRF_TAB_INTS);
     }
     hm->mrf.push_back(ms);
   }

@@ -6,10 +6,12 @@
 // These stages ('medium': 16 and 8 channels at 128 / 256 samples per mel frame) hold a third of the vocoder's
 // FLOPs but are far too narrow for the 32-row / 64-channel tiles of conv_mfma.h (4x the rows and up to 8x the
 // K-depth of MFMA work would be zeros), and un-fused they move 18 x 2 planes through the caches per stage at
-// 6 FLOP/B.  Here one workgroup owns T output columns of one batch row and runs all 18 convs on an LDS-resident
-// tile: the input is staged once with 64 columns of halo on either side (the three chains need 12 / 36 / 60),
-// every intermediate stays in LDS / registers, the average of the three chains is formed in registers, and one
-// [C x T] tile is written.  HBM/cache traffic per stage = one read + one write of the plane (+ 2 x 64 / T halo).
+// 6 FLOP/B.  Here a workgroup owns T output columns of one batch row and runs whole chains on an LDS-resident
+// tile: the input is staged with 64 columns of halo on either side (the three chains need 12 / 36 / 60), every
+// intermediate stays in LDS / registers, and only chain SUMS are written: two workgroups per tile, one for the
+// k = 11 chain (11/21 of the work) and one for the k = 3 + k = 7 chains (10/21), each writing one [C x T] tile;
+// the consumer adds the two planes and divides by 3 as it loads them.  Cache traffic per stage = two reads + two
+// writes of the plane (+ 2 x 64 / T halo) instead of 36.
 //
 // Arithmetic: v_mfma_f32_16x16x4_f32 (exact f32, bit-equal to an fmaf chain) — M = 16 output channels (all of
 // them; C = 8 uses half the rows), N = 16 time columns, K-dim = 4 input channels of one tap.  A = weights,
@@ -33,10 +35,13 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int MRF_HALO = 64;      // staged columns on either side of the tile (>= the deepest chain's receptive half-width)
 constexpr int MRF_MAX_STEPS = 3;  // dilation steps per chain
+constexpr int MRF_TAB_DIL = 3 * MRF_MAX_STEPS * 2;
+constexpr int MRF_TAB_INTS = MRF_TAB_DIL + 3 * MRF_MAX_STEPS;
 
 struct MrfArgs {
   const float* x;  // stage input [B][C][ld] (the upsampler's output)
-  float* y;        // stage output [B][C][ld]: the MRF average
+  float* y;        // out: rb_K0(x) + rb_K1(x)  [B][C][ld]
+  float* y2;       // out: rb_K2(x), same geometry; the consumer forms (y + y2) / 3
   long long bs;
   int ld;
   const int* len;  // valid length of row b = len ? len[b] * len_mul : len_const
@@ -44,113 +49,103 @@ struct MrfArgs {
   int len_const;
   const float* w;     // packed A fragments, see pack_mrf_conv (weights_pack.h)
   const float* bias;  // [chain][step][conv][16], zero padded
-  int woff[3][MRF_MAX_STEPS][2];  // float offset of each conv's fragments in w
-  int dil[3][MRF_MAX_STEPS];      // conv1 dilation of each step (conv2 has dilation 1)
+  // device table (indexed with run-time chain / step: by-value kernel-argument arrays would be copied to scratch):
+  //   tab[(chain * MRF_MAX_STEPS + step) * 2 + conv] = float offset of that conv's fragments in w,
+  //   tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + step] = conv1's dilation of that step (conv2 has dilation 1)
+  const int* tab;
   int nsteps;
   float slope;
 };
 
 // acc[s] += conv taps over one staged source for the wave's first NB slots.
+//   an   : tap 0's A fragments, already requested by the caller (a conv's first weights are cold in L1: they are
+//          asked for while the PREVIOUS conv's epilogue runs)
 //   wp   : this conv's fragments + lane          ([tap][C/4][64] floats)
 //   src  : LDS source ([C][W], lrelu already applied)
 //   boff : per slot, (lane >> 4) * W + 16 * block + (lane & 15)  (the B element of tap offset 0, channel quad 0)
 //   t0   : tap 0's column offset (-pad);  taps are `dil` columns apart
 template <int K, int C, int W, int NB, int NS>
-__device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], const float* __restrict__ wp, const float* __restrict__ src,
-                                              const int (&boff)[NS], const int t0, const int dil) {
+__device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], float (&an)[C / 4], const float* __restrict__ wp,
+                                              const float* __restrict__ src, const int (&boff)[NS], const int t0, const int dil) {
   constexpr int CQ = C / 4;
-  float an[CQ];
+  constexpr int STEPS = K * CQ;  // one step = one (tap, channel quad) = NB MFMAs, one per slot
+  // Software pipeline, written out: the B operands of step u + 1 (NB ds_read_b32) and the A fragment of the same quad
+  // one tap ahead (one global load) are requested in the shadow of step u's MFMAs — one request pinned behind each
+  // MFMA — and nothing moves across a step boundary, which bounds the live registers to two steps' operands.
+  // (Left alone the compiler hoists operands of many steps ahead: 231 registers, or spills under a 168 cap.)
+  float bcur[NB], bnxt[NB];
 #pragma unroll
-  for (int q = 0; q < CQ; ++q) an[q] = wp[q * 64];
+  for (int s = 0; s < NB; ++s) bcur[s] = src[t0 + boff[s]];
 #pragma unroll
-  for (int tap = 0; tap < K; ++tap) {
-    float ac[CQ];
+  for (int u = 0; u < STEPS; ++u) {
+    const int tap = u / CQ, q = u % CQ;
+    const float av = an[q];
+    if (tap + 1 < K) an[q] = wp[((tap + 1) * CQ + q) * 64];
+    if (u + 1 < STEPS) {
+      const int tap1 = (u + 1) / CQ, q1 = (u + 1) % CQ;
+      const float* st = src + t0 + tap1 * dil + q1 * 4 * W;
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) ac[q] = an[q];
-    if (tap + 1 < K) {
-#pragma unroll
-      for (int q = 0; q < CQ; ++q) an[q] = wp[((tap + 1) * CQ + q) * 64];
+      for (int s = 0; s < NB; ++s) bnxt[s] = st[boff[s]];
     }
-    const float* st = src + t0 + tap * dil;
 #pragma unroll
-    for (int q = 0; q < CQ; ++q)
+    for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[s], acc[s], 0, 0, 0);
+    // issue order (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
 #pragma unroll
-      for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q], st[boff[s] + q * 4 * W], acc[s], 0, 0, 0);
+    for (int s = 0; s < NB; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (s == 0 && tap + 1 < K) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (u + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 < STEPS) {
+#pragma unroll
+      for (int s = 0; s < NB; ++s) bcur[s] = bnxt[s];
+    }
   }
 }
 
-template <int C, int T, int NW, int K0, int K1, int K2>
+template <int C, int T, int NW>
 struct MrfGeom {
   static constexpr int W = T + 2 * MRF_HALO + 16;  // LDS row stride: = 16 (mod 32) floats -> B reads of 4 rows x 16 columns hit 64 distinct banks
   static constexpr int NCOL = T + 2 * MRF_HALO;    // staged columns
   static constexpr int CORE = T / 16 / NW;         // core slots per wave
   static constexpr int HS = (2 * MRF_HALO / 16 + NW - 1) / NW;  // halo slots per wave
   static constexpr int NS = CORE + HS;
-  // + slack: edge blocks of a conv read up to (K-1)/2*d columns past the staged row (values only garbage columns use)
-  static constexpr int LDS_FLOATS = 3 * C * W + 64;
+  // two planes (conv1's and conv2's operands) + slack: edge blocks of a conv read up to (K-1)/2*d columns past the
+  // staged row (values only garbage columns use)
+  static constexpr int LDS_FLOATS = 2 * C * W + 64;
   static_assert(T % (16 * NW) == 0 && W % 32 == 16 && HS >= 1 && HS <= 2, "tile geometry");
   static_assert(C == 8 || C == 16, "one 16-row MFMA block of output channels");
 };
 
+// grid = (tiles, 2, B).  blockIdx.y = 0: the K2 chain alone -> y2;  1: the K0 then the K1 chain, summed -> y.
+// The consumer forms (y + y2) / 3 = ((rb_K0 + rb_K1) + rb_K2) / 3 — the reference's summation order — when it loads
+// its input (ConvArgs::x2 / in_div).  Two workgroup kinds of 10/21 and 11/21 of a tile's work instead of one
+// workgroup per tile: twice the workgroups of half the duration (a launch is only 1.2 - 4 tiles per CU deep).
 template <int C, int T, int NW, int K0, int K1, int K2>
-__global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
-  using G = MrfGeom<C, T, NW, K0, K1, K2>;
-  constexpr int W = G::W, CORE = G::CORE, HS = G::HS, NS = G::NS;
+__global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_kernel(const MrfArgs a) {
+  using G = MrfGeom<C, T, NW>;
+  constexpr int W = G::W, CORE = G::CORE, HS = G::HS, NS = G::NS, CQ = C / 4;
   constexpr int NT = 64 * NW;
   __shared__ float lds[G::LDS_FLOATS];
-  float* const X0 = lds;           // raw stage input (all three chains start from it)
-  float* const XL = lds + C * W;   // lrelu(current x of the running chain): conv1's operand
-  float* const TB = lds + 2 * C * W;  // lrelu(conv1 + bias): conv2's operand
+  float* const XL = lds;          // lrelu(current x of the running chain): conv1's operand
+  float* const TB = lds + C * W;  // lrelu(conv1 + bias): conv2's operand
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int b = blockIdx.z;
+  const int part = blockIdx.y;
   int tile_x, tile_y;
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
   const int gx = gridDim.z > 1 ? row_tiles(L, T) : (int)gridDim.x;  // ragged batch: this row's own tiles only (conv_mfma.h)
   if ((int)blockIdx.x >= gx) return;
-  xcd_tile_lin(blockIdx.x, gx, 1, tile_x, tile_y);  // neighbouring tiles share their halo through one XCD's L2
+  xcd_tile_lin(blockIdx.x, gx, 1, tile_x, tile_y);  // neighbouring tiles (and the two parts of a tile) share their input through one XCD's L2
   const int j0 = tile_x * T;
   if (j0 >= L) return;
   const int gx0 = j0 - MRF_HALO;  // global column of LDS column 0
   const float slope = a.slope;
   const float* xb = a.x + (long long)b * a.bs;
-
-  // ---- stage the input tile: X0 = x, XL = lrelu(x), zero outside the sequence (16-byte loads, branch-free)
-  {
-    constexpr int F4 = G::NCOL / 4;
-    constexpr int NF4 = C * F4;
-    constexpr int NE = (NF4 + NT - 1) / NT;
-    const int ld_last4 = a.ld - 4;
-    float4 pre[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + NT * i;
-      const int row = e / F4, f = e - row * F4;
-      const int c0 = gx0 + 4 * f;
-      pre[i] = *reinterpret_cast<const float4*>(xb + (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
-    }
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + NT * i;
-      const int row = e / F4, f = e - row * F4;
-      const int c0 = gx0 + 4 * f;
-      float4 v = pre[i];
-      v.x = (c0 >= 0 && c0 < L) ? v.x : 0.f;
-      v.y = (c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
-      v.z = (c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
-      v.w = (c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
-      if (e < NF4) {
-        *reinterpret_cast<float4*>(X0 + row * W + 4 * f) = v;
-        v.x = v.x > 0.f ? v.x : v.x * slope;
-        v.y = v.y > 0.f ? v.y : v.y * slope;
-        v.z = v.z > 0.f ? v.z : v.z * slope;
-        v.w = v.w > 0.f ? v.w : v.w * slope;
-        *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
-      }
-    }
-  }
 
   // ---- this wave's slots: core blocks first, then its halo blocks, nearest to the core first
   // halo entry e = wave + NW*h: even -> left block 3 - e/2, odd -> right block 4 + T/16 + e/2
@@ -179,35 +174,74 @@ __global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
   floatx4 sum[CORE];
   floatx4 xres[NS];
   floatx4 acc[NS];
+  float an[CQ];  // tap 0's A fragments of the NEXT conv, requested one epilogue ahead
+  float bn[4];   // its bias
 
-  auto run_chain = [&](auto kc, const int chain) {
+  // chain start: XL = lrelu(x) for the whole tile (16-byte loads, branch-free, zero outside the sequence) and the raw
+  // residual stream of the owned positions straight from global memory (L2-hot: the tile was just read)
+  auto stage = [&]() __attribute__((always_inline)) {
+    constexpr int F4 = G::NCOL / 4;
+    constexpr int NF4 = C * F4;
+    constexpr int NE = (NF4 + NT - 1) / NT;
+    const int ld_last4 = a.ld - 4;
+    float4 pre[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      pre[i] = *reinterpret_cast<const float4*>(xb + (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int g = gx0 + 16 * blk[s] + colq;
+      const float* xp = xb + (inside[s] ? g : 0) + (rows_ok ? row0 : 0) * a.ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[s][r] = xp[r * a.ld];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      float4 v = pre[i];
+      v.x = (c0 >= 0 && c0 < L) ? v.x : 0.f;
+      v.y = (c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+      v.z = (c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+      v.w = (c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+      v.x = v.x > 0.f ? v.x : v.x * slope;
+      v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope;
+      v.w = v.w > 0.f ? v.w : v.w * slope;
+      if (e < NF4) *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[s][r] = (inside[s] && rows_ok) ? xres[s][r] : 0.f;
+  };
+  auto prefetch = [&](int chain, int step, int cv) __attribute__((always_inline)) {  // tap 0's fragments and the bias of conv (chain, step, cv)
+    const float* wp = a.w + a.tab[(chain * MRF_MAX_STEPS + step) * 2 + cv] + lane;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) an[q] = wp[q * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bn[r] = a.bias[((chain * MRF_MAX_STEPS + step) * 2 + cv) * 16 + row0 + r];
+  };
+
+  // one ResBlock1 chain; `first` = it starts this workgroup's sum, `next_chain` >= 0 = the chain that follows (its first
+  // weights are requested during this chain's last epilogue)
+  auto run_chain = [&](auto kc, const int chain, const bool first, const int next_chain) __attribute__((always_inline)) {
     constexpr int K = decltype(kc)::value;
     constexpr int P2 = (K - 1) / 2;
     // remaining halo after each conv of this chain (what later convs still need on either side)
     int need = 0;
-    for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.dil[chain][s] + 1);
-    if (chain > 0) {
-      // chain start: XL = lrelu(X0).  (No barrier needed first: the previous chain's conv1s — XL's only readers —
-      // all ended on a barrier, and its last conv2 reads TB only.)
-      for (int e = tid; e < C * (G::NCOL / 4); e += NT) {
-        const int row = e / (G::NCOL / 4), f = e - row * (G::NCOL / 4);
-        float4 v = *reinterpret_cast<const float4*>(X0 + row * W + 4 * f);
-        v.x = v.x > 0.f ? v.x : v.x * slope;
-        v.y = v.y > 0.f ? v.y : v.y * slope;
-        v.z = v.z > 0.f ? v.z : v.z * slope;
-        v.w = v.w > 0.f ? v.w : v.w * slope;
-        *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
-      }
-    }
+    for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + s] + 1);
+    // (no barrier before re-staging XL: the previous chain's conv1s — XL's only readers — all ended on a barrier,
+    //  and its last conv2 reads TB only)
+    stage();
     __syncthreads();
-    // residual stream of the owned positions
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xres[s][r] = rows_ok ? X0[(row0 + r) * W + 16 * blk[s] + colq] : 0.f;
-
     for (int step = 0; step < a.nsteps; ++step) {
-      const int dil = a.dil[chain][step];
+      const int dil = a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + step];
       const bool last = step == a.nsteps - 1;
 #pragma unroll
       for (int cv = 0; cv < 2; ++cv) {
@@ -218,18 +252,22 @@ __global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
         int nh = 0;
 #pragma unroll
         for (int h = 0; h < HS; ++h) nh += (wave + NW * h) < n_act ? 1 : 0;
-        const float* wp = a.w + a.woff[chain][step][cv] + lane;
+        const float* wp = a.w + a.tab[(chain * MRF_MAX_STEPS + step) * 2 + cv] + lane;
         const float* src = cv == 0 ? XL : TB;
+        float bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[r] = bn[r];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
         // wave-uniform slot count -> one instantiation of the MFMA loop per count
-        if (HS >= 2 && nh >= 2) mrf_conv_taps<K, C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, wp, src, boff, -P2 * d, d);
-        else if (nh >= 1) mrf_conv_taps<K, C, W, CORE + 1, NS>(acc, wp, src, boff, -P2 * d, d);
-        else mrf_conv_taps<K, C, W, CORE, NS>(acc, wp, src, boff, -P2 * d, d);
+        if (HS >= 2 && nh >= 2) mrf_conv_taps<K, C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, an, wp, src, boff, -P2 * d, d);
+        else if (nh >= 1) mrf_conv_taps<K, C, W, CORE + 1, NS>(acc, an, wp, src, boff, -P2 * d, d);
+        else mrf_conv_taps<K, C, W, CORE, NS>(acc, an, wp, src, boff, -P2 * d, d);
         const int nb = CORE + nh;
-        float bb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bb[r] = a.bias[((chain * MRF_MAX_STEPS + step) * 2 + cv) * 16 + row0 + r];
+        // the next conv's first weights + bias go out before this epilogue
+        if (cv == 0) prefetch(chain, step, 1);
+        else if (!last) prefetch(chain, step + 1, 0);
+        else if (next_chain >= 0) prefetch(next_chain, 0, 0);
         if (cv == 0) {
           // TB = lrelu(conv1 + bias), zero outside the sequence (conv2's zero padding)
 #pragma unroll
@@ -264,21 +302,25 @@ __global__ __launch_bounds__(64 * NW) void mrf_small_kernel(const MrfArgs a) {
 #pragma unroll
     for (int s = 0; s < CORE; ++s)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sum[s][r] = chain == 0 ? xres[s][r] : sum[s][r] + xres[s][r];
+      for (int r = 0; r < 4; ++r) sum[s][r] = first ? xres[s][r] : sum[s][r] + xres[s][r];
   };
-  run_chain(std::integral_constant<int, K0>{}, 0);
-  run_chain(std::integral_constant<int, K1>{}, 1);
-  run_chain(std::integral_constant<int, K2>{}, 2);
+  if (part == 0) {
+    prefetch(2, 0, 0);
+    run_chain(std::integral_constant<int, K2>{}, 2, true, -1);
+  } else {
+    prefetch(0, 0, 0);
+    run_chain(std::integral_constant<int, K0>{}, 0, true, 1);
+    run_chain(std::integral_constant<int, K1>{}, 1, false, -1);
+  }
 
-  // ---- y = sum / 3
   if (rows_ok) {
-    float* yb = a.y + (long long)b * a.bs;
+    float* yb = (part == 0 ? a.y2 : a.y) + (long long)b * a.bs;
 #pragma unroll
     for (int s = 0; s < CORE; ++s) {
       const int g = gx0 + 16 * blk[s] + colq;
       if (g < L) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yb[(long long)(row0 + r) * a.ld + g] = sum[s][r] / 3.0f;
+        for (int r = 0; r < 4; ++r) yb[(long long)(row0 + r) * a.ld + g] = sum[s][r];
       }
     }
   }
