@@ -578,25 +578,13 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   a.tab = reinterpret_cast<const int*>(arena + ms.t_off);
   a.nsteps = ms.nsteps;
   a.slope = 0.1f;
-  static const int t_env = [] { const char* e = std::getenv("MI355TTS_MRF_T"); return e ? std::atoi(e) : 0; }();
-  // tile: 256 columns at C = 16 (77 KB of LDS, two workgroups per CU); 512 at C = 8 unless that leaves CUs without a tile
-  int T = ms.C == 16 ? 256 : ((long long)((Lmax + 511) / 512) * B >= 512 ? 512 : 256);
-  if (t_env == 256 || (t_env == 512 && ms.C == 8)) T = t_env;
-  const dim3 grid((Lmax + T - 1) / T, 2, B);
+  // 256-column tiles: 2 x C x 400 floats of LDS (51 KB at C = 16, 26 KB at C = 8) -> three workgroups per CU.  (512-column
+  // tiles measured no better at either width: tools/probe/mrf_bench.hip, profiles/NOTES.md.)
+  constexpr int T = 256;
+  const dim3 grid(2 * ((Lmax + T - 1) / T), 1, B);  // two workgroups per tile
   ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
-  static const int nw_env = [] { const char* e = std::getenv("MI355TTS_MRF_NW"); return e ? std::atoi(e) : 0; }();
-  if (nw_env == 8) {  // experiment: 8 waves per workgroup
-    if (ms.C == 16 && t_env == 512) {
-      const dim3 g2((Lmax + 511) / 512, 2, B);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 512, 8, 3, 7, 11>), g2, dim3(512), 0, s, a);
-    } else if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 256, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
-    else if (T == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 512, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 256, 8, 3, 7, 11>), grid, dim3(512), 0, s, a);
-    return 0;
-  }
-  if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
-  else if (T == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 512, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, 256, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   return 0;
 }
 

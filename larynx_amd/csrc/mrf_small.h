@@ -38,6 +38,12 @@ constexpr int MRF_MAX_STEPS = 3;  // dilation steps per chain
 constexpr int MRF_TAB_DIL = 3 * MRF_MAX_STEPS * 2;
 constexpr int MRF_TAB_INTS = MRF_TAB_DIL + 3 * MRF_MAX_STEPS;
 
+// probe builds (tools/probe/mrf_bench.hip -DMRF_ABL=bits; results are WRONG when set): 1 = no B operand reads in the MFMA
+// loop, 2 = no barriers, 4 = epilogue LDS stores skipped at run time, 8 = no A fragment loads in the loop, 32 = MFMA loops skipped at run time
+#ifndef MRF_ABL
+#define MRF_ABL 0
+#endif
+
 struct MrfArgs {
   const float* x;  // stage input [B][C][ld] (the upsampler's output)
   float* y;        // out: rb_K0(x) + rb_K1(x)  [B][C][ld]
@@ -64,43 +70,61 @@ struct MrfArgs {
 //   src  : LDS source ([C][W], lrelu already applied)
 //   boff : per slot, (lane >> 4) * W + 16 * block + (lane & 15)  (the B element of tap offset 0, channel quad 0)
 //   t0   : tap 0's column offset (-pad);  taps are `dil` columns apart
-template <int K, int C, int W, int NB, int NS>
+template <int C, int W, int NB, int NS>
 __device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], float (&an)[C / 4], const float* __restrict__ wp,
-                                              const float* __restrict__ src, const int (&boff)[NS], const int t0, const int dil) {
+                                              const float* __restrict__ src, const int (&boff)[NS], const int t0, const int dil, const int K) {
   constexpr int CQ = C / 4;
-  constexpr int STEPS = K * CQ;  // one step = one (tap, channel quad) = NB MFMAs, one per slot
-  // Software pipeline, written out: the B operands of step u + 1 (NB ds_read_b32) and the A fragment of the same quad
-  // one tap ahead (one global load) are requested in the shadow of step u's MFMAs — one request pinned behind each
-  // MFMA — and nothing moves across a step boundary, which bounds the live registers to two steps' operands.
-  // (Left alone the compiler hoists operands of many steps ahead: 231 registers, or spills under a 168 cap.)
+  // One step = one (tap, channel quad) = NB MFMAs, one per slot.  Software pipeline, written out: the B operands of
+  // the next step (NB ds_read_b32) and the A fragment of the same quad one tap ahead (one global load) are requested
+  // in the shadow of this step's MFMAs — one request pinned behind each MFMA — and nothing moves across a step
+  // boundary, which bounds the live registers to two steps' operands.  The tap loop is a real loop (K is a run-time
+  // value): unrolled over (K, NB) the kernel was ~100 KB of straight-line code for a 64 KB instruction cache that
+  // two CUs share.  On the last tap the prefetches read one tap too far: the next conv's fragments (inside the
+  // weight arena) and columns inside the LDS slack — values nothing uses.
+  int bo[NB];
   float bcur[NB], bnxt[NB];
 #pragma unroll
-  for (int s = 0; s < NB; ++s) bcur[s] = src[t0 + boff[s]];
+  for (int s = 0; s < NB; ++s) {
+    bo[s] = boff[s] + t0;
+    bcur[s] = src[bo[s]];
+  }
+  const float* wt = wp + CQ * 64;  // the next tap's fragments
+  const int taps = ((MRF_ABL & 32) && dil < 99) ? 0 : K;
+#pragma unroll 1
+  for (int tap = 0; tap < taps; ++tap) {
 #pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    const int tap = u / CQ, q = u % CQ;
-    const float av = an[q];
-    if (tap + 1 < K) an[q] = wp[((tap + 1) * CQ + q) * 64];
-    if (u + 1 < STEPS) {
-      const int tap1 = (u + 1) / CQ, q1 = (u + 1) % CQ;
-      const float* st = src + t0 + tap1 * dil + q1 * 4 * W;
+    for (int q = 0; q < CQ; ++q) {
+      const float av = an[q];
+      if (!(MRF_ABL & 8)) an[q] = wt[q * 64];
+      if (MRF_ABL & 64) {
 #pragma unroll
-      for (int s = 0; s < NB; ++s) bnxt[s] = st[boff[s]];
-    }
+        for (int s = 0; s < NB; ++s) bnxt[s] = bcur[s];
+      } else if (MRF_ABL & 1) {
 #pragma unroll
-    for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[s], acc[s], 0, 0, 0);
-    // issue order (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
+        for (int s = 0; s < NB; ++s) bnxt[s] = bcur[s] + 1.0f;
+      } else if (q + 1 < CQ) {
 #pragma unroll
-    for (int s = 0; s < NB; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (s == 0 && tap + 1 < K) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      if (u + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (u + 1 < STEPS) {
+        for (int s = 0; s < NB; ++s) bnxt[s] = src[bo[s] + (q + 1) * 4 * W];
+      } else {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) bo[s] += dil;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) bnxt[s] = src[bo[s]];
+      }
+#pragma unroll
+      for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[s], acc[s], 0, 0, 0);
+      // issue order (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (s == 0 && !(MRF_ABL & 8)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (!(MRF_ABL & 65)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < NB; ++s) bcur[s] = bnxt[s];
     }
+    wt += CQ * 64;
   }
 }
 
@@ -111,9 +135,9 @@ struct MrfGeom {
   static constexpr int CORE = T / 16 / NW;         // core slots per wave
   static constexpr int HS = (2 * MRF_HALO / 16 + NW - 1) / NW;  // halo slots per wave
   static constexpr int NS = CORE + HS;
-  // two planes (conv1's and conv2's operands) + slack: edge blocks of a conv read up to (K-1)/2*d columns past the
-  // staged row (values only garbage columns use)
-  static constexpr int LDS_FLOATS = 2 * C * W + 64;
+  // two planes (conv1's and conv2's operands) + slack on either side: edge blocks of a conv read up to
+  // ((K-1)/2 + 1)*d columns before / past the staged rows (values only garbage columns use)
+  static constexpr int LDS_FLOATS = 64 + 2 * C * W + 64;
   static_assert(T % (16 * NW) == 0 && W % 32 == 16 && HS >= 1 && HS <= 2, "tile geometry");
   static_assert(C == 8 || C == 16, "one 16-row MFMA block of output channels");
 };
@@ -122,25 +146,38 @@ struct MrfGeom {
 // The consumer forms (y + y2) / 3 = ((rb_K0 + rb_K1) + rb_K2) / 3 — the reference's summation order — when it loads
 // its input (ConvArgs::x2 / in_div).  Two workgroup kinds of 10/21 and 11/21 of a tile's work instead of one
 // workgroup per tile: twice the workgroups of half the duration (a launch is only 1.2 - 4 tiles per CU deep).
+#ifndef MRF_MIX
+#define MRF_MIX 256
+#endif
+#ifndef MRF_OCC
+#define MRF_OCC(T, NW) ((T) / (NW) <= 64 ? 3 : 2)  // waves per SIMD the register allocation aims at (tools/probe/mrf_bench.hip overrides)
+#endif
 template <int C, int T, int NW, int K0, int K1, int K2>
-__global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_kernel(const MrfArgs a) {
+__global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(const MrfArgs a) {
   using G = MrfGeom<C, T, NW>;
   constexpr int W = G::W, CORE = G::CORE, HS = G::HS, NS = G::NS, CQ = C / 4;
   constexpr int NT = 64 * NW;
   __shared__ float lds[G::LDS_FLOATS];
-  float* const XL = lds;          // lrelu(current x of the running chain): conv1's operand
-  float* const TB = lds + C * W;  // lrelu(conv1 + bias): conv2's operand
+  float* const XL = lds + 64;     // lrelu(current x of the running chain): conv1's operand
+  float* const TB = XL + C * W;   // lrelu(conv1 + bias): conv2's operand
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int b = blockIdx.z;
-  const int part = blockIdx.y;
   int tile_x, tile_y;
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
-  const int gx = gridDim.z > 1 ? row_tiles(L, T) : (int)gridDim.x;  // ragged batch: this row's own tiles only (conv_mfma.h)
-  if ((int)blockIdx.x >= gx) return;
-  xcd_tile_lin(blockIdx.x, gx, 1, tile_x, tile_y);  // neighbouring tiles (and the two parts of a tile) share their input through one XCD's L2
+  const int gx = gridDim.z > 1 ? row_tiles(L, T) : (int)gridDim.x / 2;  // ragged batch: this row's own tiles only (conv_mfma.h)
+  // 1-D grid of 2 * tiles workgroups: runs of MRF_MIX "k = 11" workgroups alternate with runs of MRF_MIX "k = 3 + 7"
+  // ones, so that the workgroups that end up sharing a CU (dispatch order: one per CU, then the second, ...) are of
+  // both kinds and at different points of their conv sequence — workgroups of one kind started together run their
+  // MFMA loops and their epilogues in lockstep and cannot cover for each other.
+  const int lin = blockIdx.x;
+  if (lin >= 2 * gx) return;
+  const int chunk = lin / (2 * MRF_MIX), r = lin - chunk * (2 * MRF_MIX);
+  const int n_in = gx - chunk * MRF_MIX < MRF_MIX ? gx - chunk * MRF_MIX : MRF_MIX;
+  const int part = r / n_in;
+  xcd_tile_lin(chunk * MRF_MIX + (r - part * n_in), gx, 1, tile_x, tile_y);  // neighbouring tiles (and a tile's two parts) share their input through one XCD's L2
   const int j0 = tile_x * T;
   if (j0 >= L) return;
   const int gx0 = j0 - MRF_HALO;  // global column of LDS column 0
@@ -230,9 +267,8 @@ __global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_ker
 
   // one ResBlock1 chain; `first` = it starts this workgroup's sum, `next_chain` >= 0 = the chain that follows (its first
   // weights are requested during this chain's last epilogue)
-  auto run_chain = [&](auto kc, const int chain, const bool first, const int next_chain) __attribute__((always_inline)) {
-    constexpr int K = decltype(kc)::value;
-    constexpr int P2 = (K - 1) / 2;
+  auto run_chain = [&](const int K, const int chain, const bool first, const int next_chain) __attribute__((always_inline)) {
+    const int P2 = (K - 1) / 2;
     // remaining halo after each conv of this chain (what later convs still need on either side)
     int need = 0;
     for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + s] + 1);
@@ -257,12 +293,13 @@ __global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_ker
         float bb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bb[r] = bn[r];
+        // accumulators start at the bias (one VALU op less per output than adding it in the epilogue)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < NS; ++s) acc[s] = floatx4{bb[0], bb[1], bb[2], bb[3]};
         // wave-uniform slot count -> one instantiation of the MFMA loop per count
-        if (HS >= 2 && nh >= 2) mrf_conv_taps<K, C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, an, wp, src, boff, -P2 * d, d);
-        else if (nh >= 1) mrf_conv_taps<K, C, W, CORE + 1, NS>(acc, an, wp, src, boff, -P2 * d, d);
-        else mrf_conv_taps<K, C, W, CORE, NS>(acc, an, wp, src, boff, -P2 * d, d);
+        if (HS >= 2 && nh >= 2) mrf_conv_taps<C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, an, wp, src, boff, -P2 * d, d, K);
+        else if (nh >= 1) mrf_conv_taps<C, W, CORE + 1, NS>(acc, an, wp, src, boff, -P2 * d, d, K);
+        else mrf_conv_taps<C, W, CORE, NS>(acc, an, wp, src, boff, -P2 * d, d, K);
         const int nb = CORE + nh;
         // the next conv's first weights + bias go out before this epilogue
         if (cv == 0) prefetch(chain, step, 1);
@@ -275,9 +312,9 @@ __global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_ker
             if (s < nb && rows_ok) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float v = acc[s][r] + bb[r];
+                float v = acc[s][r];
                 v = v > 0.f ? v : v * slope;
-                TB[(row0 + r) * W + 16 * blk[s] + colq] = inside[s] ? v : 0.f;
+                if (!(MRF_ABL & 4) || a.nsteps == 99) TB[(row0 + r) * W + 16 * blk[s] + colq] = inside[s] ? v : 0.f;
               }
             }
           }
@@ -288,14 +325,14 @@ __global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_ker
             if (s < nb) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float v = inside[s] ? (acc[s][r] + bb[r]) + xres[s][r] : 0.f;
+                const float v = inside[s] ? acc[s][r] + xres[s][r] : 0.f;
                 xres[s][r] = v;
-                if (!last && rows_ok) XL[(row0 + r) * W + 16 * blk[s] + colq] = v > 0.f ? v : v * slope;
+                if (!last && rows_ok && (!(MRF_ABL & 4) || a.nsteps == 99)) XL[(row0 + r) * W + 16 * blk[s] + colq] = v > 0.f ? v : v * slope;
               }
             }
           }
         }
-        if (!(last && cv == 1)) __syncthreads();
+        if (!(last && cv == 1) && !(MRF_ABL & 2)) __syncthreads();
       }
     }
     // the MRF sum, in the reference's order (xs = rb0; xs += rb1; xs += rb2)
@@ -306,11 +343,11 @@ __global__ __launch_bounds__(64 * NW, (T / NW <= 64) ? 3 : 2) void mrf_small_ker
   };
   if (part == 0) {
     prefetch(2, 0, 0);
-    run_chain(std::integral_constant<int, K2>{}, 2, true, -1);
+    run_chain(K2, 2, true, -1);
   } else {
     prefetch(0, 0, 0);
-    run_chain(std::integral_constant<int, K0>{}, 0, true, 1);
-    run_chain(std::integral_constant<int, K1>{}, 1, false, -1);
+    run_chain(K0, 0, true, 1);
+    run_chain(K1, 1, false, -1);
   }
 
   if (rows_ok) {

@@ -382,7 +382,8 @@ def test_shortest_utterances_full_size_models(gpu_engine, n_ids):
 def test_bf16x3_mode_against_the_reference(gpu_engine, name):
     """The reference's `half` switch on this backend = split-bf16 ResBlock convs (conv_bf16.h).  Documented
     tolerance vs the reference's f32 output: waveform RMS <= 1e-4 (north_star's f32 bar still holds — the
-    split keeps 16 mantissa bits per operand and accumulates in f32), int16 within 8 LSB; the exact mode is
+    split keeps 16 mantissa bits per operand and accumulates in f32), int16 within 1 LSB (measured on every golden:
+    RMS 0.5-1.7e-6, 1 LSB — the bound bench.py / README / DESIGN quote is the one asserted here); the exact mode is
     untouched by switching back and forth."""
     from larynx_amd import ffi
 
@@ -403,7 +404,33 @@ def test_bf16x3_mode_against_the_reference(gpu_engine, name):
     print(f"bf16x3 {name}: rms {rms:.3e} max {mx:.3e} int16 {d16} LSB")
     if c["voc_hp"].upsample_initial_channel >= 128:
         assert not np.array_equal(exact, wav)  # the mode ran (stages with >= 64 channels exist)
-    assert rms <= WAV_RMS_TOL and d16 <= 8, (rms, mx, d16)
+    assert rms <= WAV_RMS_TOL and d16 <= 1, (rms, mx, d16)
+
+
+@pytest.mark.parametrize("name", ["ljspeech_high_S120", "ljspeech_medium_dave_ls12"])
+def test_bf16x3_fused_call_against_the_reference(gpu_engine, name):
+    """The path `half=True` really takes — ids -> ONE fused `mi355tts_synthesize` call with the vocoder in split-bf16
+    mode (what bench.py's half_mode leg times) — against the reference's f32 golden: frames identical, waveform RMS
+    within north_star's 1e-4, int16 within 1 LSB."""
+    from larynx_amd import ffi
+
+    c = load_case(name)
+    (gsd, g), (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    s = ljspeech_audio_settings()
+    gpu_engine.set_precision(v, ffi.PRECISION_BF16X3)
+    gpu_engine.set_precision(g, ffi.PRECISION_BF16X3)
+    try:
+        frames, wav, i16 = gpu_engine.synthesize(g, v, c["ids"], float(c["noise_scale"]), float(c["length_scale"]), noise=c["noise"],
+                                                 audio_settings=s, want_float=True)
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+        gpu_engine.set_precision(g, ffi.PRECISION_F32)
+    assert int(frames[0]) == c["mel"].shape[1]
+    n = c["wav"].shape[0]
+    rms = float(np.sqrt(np.mean((wav[0, :n] - c["wav"]) ** 2)))
+    d16 = int(np.abs(i16[0, :n].astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
+    print(f"bf16x3 fused {name}: rms {rms:.3e} int16 {d16} LSB")
+    assert rms <= WAV_RMS_TOL and d16 <= 1, (rms, d16)
 
 
 def test_plain_bf16_mode_documented_tolerance(gpu_engine):
