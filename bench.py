@@ -53,17 +53,19 @@ def algorithmic_flop(P: int, F: float, quality: str = "high") -> float:
 
 def cpu_baseline(ids: np.ndarray, length_scale: float, max_seconds: float = 45.0):
     """The CPU oracle timed on this box's host cores on the SAME utterance the GPU leg times
-    first (BASELINE config 2 at S: 120 ids -> ~600 frames): GlowTTS (numpy oracle) + mel
-    transforms + HiFi-GAN 'high' (the oracle restated on torch CPU operators,
-    oracle/hifi_gan_torch.py — the same oneDNN kernels the reference's own `--backend pytorch`
-    path uses) + int16 conversion.  Thread count: best of a short sweep; then >= 5 timed runs
-    at that count (min and median) and one single-thread run."""
+    first (BASELINE config 2 at S: 120 ids -> ~600 frames), end to end on torch CPU operators —
+    GlowTTS (oracle/glow_tts_torch.py) + mel transforms + HiFi-GAN 'high' (oracle/hifi_gan_torch.py):
+    the conv / matmul / softmax kernels (oneDNN, MKL) the reference's own `--backend pytorch`
+    path runs on, wrapped like `_sentence_task` — + int16 conversion.  Both
+    ports are pinned to the numpy oracle, which is pinned to the reference's modules.  Thread
+    count: best of a short sweep; then >= 5 timed runs at that count (min and median) and one
+    single-thread run."""
     import torch
 
     from larynx_amd import hparams as HP
     from larynx_amd import synthetic
     from larynx_amd.audio import ljspeech_audio_settings
-    from oracle import audio_np, glow_tts_np, hifi_gan_torch
+    from oracle import audio_np, glow_tts_torch, hifi_gan_torch
 
     gsd = synthetic.make_glow_state_dict(HP.LJSPEECH, seed=1234)
     vsd = synthetic.make_hifigan_state_dict(HP.HIFIGAN_HIGH, seed=1234)
@@ -74,7 +76,7 @@ def cpu_baseline(ids: np.ndarray, length_scale: float, max_seconds: float = 45.0
     def once(threads):
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        mel = glow_tts_np.glow_tts_infer(gsd, HP.LJSPEECH, ids, noise, 0.667, length_scale)
+        mel = glow_tts_torch.glow_tts_infer_torch(gsd, HP.LJSPEECH, ids, noise, 0.667, length_scale, threads=threads)
         wav = hifi_gan_torch.hifigan_infer_torch(vsd, HP.HIFIGAN_HIGH, audio_np.mel_to_vocoder_input(mel, s), threads=threads)
         audio_np.audio_float_to_int16(wav)
         return time.perf_counter() - t0, mel.shape[1]
@@ -111,10 +113,36 @@ def cpu_baseline(ids: np.ndarray, length_scale: float, max_seconds: float = 45.0
         "rtf_1_thread": (one_thread / audio_s) if one_thread else None,
         "x_realtime": audio_s / best,
         "thread_sweep_seconds": {str(k): v for k, v in sweep.items()},
-        "sample": f"CPU oracle (GlowTTS: numpy/OpenBLAS; HiFi-GAN 'high': torch CPU operators) on the benchmark's own first "
+        "sample": f"CPU oracle on torch CPU operators end to end (GlowTTS + mel transforms + HiFi-GAN 'high' + int16: the arithmetic of the "
+                  f"reference's --backend pytorch; reported at world size 1 only) on the benchmark's own first "
                   f"utterance: {len(ids)} ids -> {F} frames = {audio_s:.2f} s audio, whole utterance per run; {best_threads} threads "
                   f"(best of a {sorted(sweep)} sweep on {ncpu} host CPUs), min / median of {len(runs)} runs = {best:.3f} / {med:.3f} s",
     }
+
+
+def pin_rank_to_gpu_numa(local: int) -> dict:
+    """Keep this rank's host threads (the ThreadPoolExecutor feeding its GPU, torch's intra-op pool) on the NUMA node its GPU
+    hangs off: /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist -> sched_setaffinity.
+    Best effort: a box without that information (or a single-node one) is left alone; what was done goes into the line."""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(Path(f"/sys/bus/pci/devices/{bdf}/numa_node").read_text().strip())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "pinned": False, "why": "the platform reports no NUMA affinity for the device"}
+        cpus = set()
+        for part in Path(f"/sys/devices/system/node/node{node}/cpulist").read_text().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pci": bdf, "numa_node": node, "pinned": False, "why": "no allowed CPU on that node"}
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception as e:  # noqa: BLE001 - placement is an optimisation, never a reason to fail the run
+        return {"pinned": False, "why": f"{type(e).__name__}: {e}"[:160]}
 
 
 def respawn_under_torchrun(n: int) -> int:
@@ -345,9 +373,12 @@ def main():
     on_gpu = args.device == "cuda"
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
+    affinity = None
     if on_gpu:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+        affinity = pin_rank_to_gpu_numa(local)
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world)))))
     else:
         dev = torch.device("cpu")
     # under torch.distributed.run (the driver's launch form) the process group is always brought up — also at
@@ -557,7 +588,11 @@ def main():
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
                           half[0] if half else 0.0, half[1] if half else 0.0], dtype=torch.float64, device=red_dev)
+    per_rank = [[float(stats[0]), float(stats[1])]]  # this rank's (in-flight, single-stream) seconds per K-step region
     if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -628,6 +663,8 @@ def main():
                 "scaling": "strong",
                 "ordered_gather_seconds": t_gather,
                 "shard_sizes": [len(x) for x in sharding.lpt_assign(lengths, world)],
+                "shard_ids": [int(sum(lengths[i] for i in x)) for x in sharding.lpt_assign(lengths, world)],
+                "shard_imbalance": float(max(sum(lengths[i] for i in x) for x in sharding.lpt_assign(lengths, world)) * world / max(1, sum(lengths))),
             }
 
     # ---- BASELINE config 5: long multi-voice text as a stream — sentences cycling three resident voices (en V=46 /
@@ -768,6 +805,13 @@ def main():
                 "resblock_class_f32_equivalent_tflops": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 if half[2]["ms"] > 0 else None,
             },
             "weight_broadcast_seconds": broadcast_s if use_dist else None,
+            "per_rank": {
+                "utterances_per_sec": [K * B / t[0] for t in per_rank],
+                "min": min(K * B / t[0] for t in per_rank), "max": max(K * B / t[0] for t in per_rank),
+                "latency_ms_single_stream": [1e3 * t[1] / K for t in per_rank],
+                "note": "each rank's own median over the repeats; `value` = all ranks' utterances / the slowest rank's time",
+            },
+            "host_affinity_rank0": affinity,
             "process_group": (("nccl (RCCL)" if rccl else ("gloo" if not on_gpu else f"gloo (RCCL init failed: {pg_note}); every rank folded its own seeded weights")) if use_dist else None),
             "roofline": {
                 "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (fused conv pairs, 64/32-channel stages)",

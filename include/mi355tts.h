@@ -131,12 +131,20 @@ int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision);
  * "input" / "input_lengths"), scales as in the reference's "scales" input.
  * noise: optional N(0,1) tensor [B][mel_channels][noise_ld] standing in for
  * torch.randn_like (glow_tts/models.py:348) — parity mode; NULL draws from a
- * counter-based generator keyed by `seed`.  `audio` (optional) additionally
+ * counter-based generator keyed by `seed` (row b of a batch: seed + b).  `audio` (optional) additionally
  * produces the vocoder-input mel (the three numpy transforms of _sentence_task).
  * The frame count is data dependent; the result stays on the device. */
 int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
                         float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
                         const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);
+
+/* The same with one noise-stream seed PER ROW (host array [B]) for the device generator: row b draws the field a
+ * batch-1 call with seed = row_seeds[b] draws, so a work list cut into micro-batches (the utterance shards of
+ * larynx/__init__.py:146-157 run as padded batches) gives every utterance the audio it gets on its own.
+ * (mi355tts_glow_infer's rows use seed + b.) */
+int mi355tts_glow_infer_rows(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                             float noise_scale, float length_scale, const uint64_t* row_seeds,
+                             const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);
 
 int mi355tts_mel_batch(const mi355tts_mel* mel);
 int mi355tts_mel_channels(const mi355tts_mel* mel);

@@ -22,15 +22,17 @@ struct GlowCall {
   const float* noise = nullptr;
   int noise_ld = 0;
   uint64_t seed = 0;
+  const uint64_t* row_seeds = nullptr;  // optional, host, [B]: the noise stream of row b (default seed + b)
   const mi355tts_audio_settings* audio = nullptr;
   uint32_t flags = 0;
 };
 
-static int find_glow(mi355tts_ctx* ctx, int glow, const GlowModel** out) {
+// pins the model: the caller's shared_ptr keeps it alive until the call returns, whatever mi355tts_unload does meanwhile
+static int find_glow(mi355tts_ctx* ctx, int glow, std::shared_ptr<GlowModel>* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto it = ctx->glow.find(glow);
   if (it == ctx->glow.end()) return fail(MI355TTS_ERR_NO_MODEL, "no GlowTTS model %d", glow);
-  *out = it->second.get();
+  *out = it->second;
   return 0;
 }
 
@@ -59,7 +61,7 @@ static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) 
 
 // Encoder workspace of one call: ONE definition for the forward pass and mi355tts_reserve.
 struct GlowEncLayout {
-  size_t o_len, o_ids, o_x, o_t1, o_t2, o_qkv, o_ffn, o_xm, o_logw, o_cum, o_sc, total;
+  size_t o_len, o_seed, o_ids, o_x, o_t1, o_t2, o_qkv, o_ffn, o_xm, o_logw, o_cum, o_sc, total;
   int P, att_rows;
 };
 static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int ids_ld, int Pmax) {
@@ -69,6 +71,7 @@ static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int 
   const int P = L.P;
   Carver cv;
   L.o_len = cv.take(sizeof(int) * B);
+  L.o_seed = cv.take(sizeof(unsigned long long) * B);
   L.o_ids = cv.take(sizeof(long long) * (size_t)B * ids_ld);
   L.o_x = cv.take(sizeof(float) * (size_t)B * H * P);
   L.o_t1 = cv.take(sizeof(float) * (size_t)B * H * P);
@@ -123,6 +126,11 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   const int k = h.kernel_size, nh = h.n_heads;
   const bool in_dev = (flags & MI355TTS_IN_DEVICE) != 0;
   const int enc_host_len = B == 1 ? id_lens[0] : -1;
+  {
+    long long sum = 0;
+    for (int b = 0; b < B; ++b) sum += id_lens[b];
+    w->flop_scale = Pmax > 0 ? (double)sum / ((double)B * Pmax) : 1.0;  // ragged batch: count the rows' real ids
+  }
 
   // ---- encoder workspace
   const GlowEncLayout el = glow_enc_layout(h, B, ids_ld, Pmax);
@@ -145,6 +153,11 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   float* sc = (float*)(base + el.o_sc);
 
   HIPCHECK(hipMemcpyAsync(d_len, id_lens, sizeof(int) * B, hipMemcpyHostToDevice, s));
+  unsigned long long* d_seeds = nullptr;
+  if (call.row_seeds) {
+    d_seeds = (unsigned long long*)(base + el.o_seed);
+    HIPCHECK(hipMemcpyAsync(d_seeds, call.row_seeds, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, s));
+  }
   HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
 
   const long long bsH = (long long)H * P;
@@ -273,6 +286,11 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   if (noise && noise_scale != 0.f && noise_ld < Fmax)
     return fail(MI355TTS_ERR_TOO_SMALL, "noise has %d columns but the utterance needs %d frames", noise_ld, Fmax);
   mel->max_frames = Fmax;
+  {
+    long long sum = 0;
+    for (int b = 0; b < B; ++b) sum += mel->frames[b];
+    w->flop_scale = Fmax > 0 ? (double)sum / ((double)B * Fmax) : 1.0;
+  }
   const int Fld = (Fmax + 3) & ~3;
   mel->ld = Fld;
   if (Fmax == 0) {
@@ -304,6 +322,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     HIPCHECK(hipMemcpy(w->arena, keep.data(), enc_bytes, hipMemcpyHostToDevice));
     base = w->arena;
     d_len = (int*)(base + o_len);
+    if (d_seeds) d_seeds = (unsigned long long*)(base + el.o_seed);
     xm = (float*)(base + o_xm);
     cum = (int*)(base + o_cum);
   }
@@ -322,8 +341,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   {
     ProfScope ps(ctx, w, KC_SMALL, 0);
     hipLaunchKernelGGL(expand_noise_squeeze_kernel, dim3((Fmax + 255) / 256, 8, B), dim3(256), 0, s, xm, (long long)M * P, P,
-                       d_len, cum, P, d_frames, d_noise, (long long)M * noise_ld, noise_ld, noise_scale, seed, M, nsq, z,
-                       bsZ, F2);
+                       d_len, cum, P, d_frames, d_noise, (long long)M * noise_ld, noise_ld, noise_scale, seed, d_seeds, M, nsq,
+                       z, bsZ, F2);
   }
   // frames/n_sqz is the decoder's time axis: len = frames[b] / nsq  -> use out_mul trick via a scaled length array
   // (frames are multiples of n_sqz; kernels take frames with a divisor where needed)
@@ -390,16 +409,18 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     HIPCHECK(hipGetLastError());
   }
   mguard.m = nullptr;
+  w->flop_scale = 1.0;
   *out = mel;
   return 0;
 }
 
-extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
-                                   float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
-                                   const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+static int glow_infer_impl(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                           float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                           const uint64_t* row_seeds, const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
   if (!ctx || !out) return fail(MI355TTS_ERR_INVALID, "null argument");
-  const GlowModel* gm = nullptr;
-  CHECK(find_glow(ctx, glow, &gm));
+  std::shared_ptr<GlowModel> gpin;
+  CHECK(find_glow(ctx, glow, &gpin));
+  const GlowModel* gm = gpin.get();
   GlowCall c;
   c.ids = ids;
   c.id_lens = id_lens;
@@ -410,6 +431,7 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   c.noise = noise;
   c.noise_ld = noise_ld;
   c.seed = seed;
+  c.row_seeds = row_seeds;
   c.audio = audio;
   c.flags = flags;
   int Pmax = 0;
@@ -419,4 +441,16 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
   CHECK(acquire_worker(ctx, &w));
   WorkerGuard guard{ctx, w};
   return glow_run(ctx, w, gm, c, Pmax, true, out);
+}
+
+extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                   float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                                   const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+  return glow_infer_impl(ctx, glow, ids, id_lens, B, ids_ld, noise_scale, length_scale, noise, noise_ld, seed, nullptr, audio, flags, out);
+}
+extern "C" int mi355tts_glow_infer_rows(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                        float noise_scale, float length_scale, const uint64_t* row_seeds,
+                                        const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+  if (!row_seeds) return fail(MI355TTS_ERR_INVALID, "row_seeds null");
+  return glow_infer_impl(ctx, glow, ids, id_lens, B, ids_ld, noise_scale, length_scale, nullptr, 0, 0, row_seeds, audio, flags, out);
 }

@@ -61,11 +61,12 @@ struct VocCall {
   int pad_before = 0, pad_after = 0;
 };
 
-static int find_hifi(mi355tts_ctx* ctx, int vocoder, HifiModel** out) {
+// pins the model (see find_glow)
+static int find_hifi(mi355tts_ctx* ctx, int vocoder, std::shared_ptr<HifiModel>* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto it = ctx->hifi.find(vocoder);
   if (it == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no HiFi-GAN model %d", vocoder);
-  *out = it->second.get();
+  *out = it->second;
   return 0;
 }
 
@@ -162,6 +163,15 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   const int C0 = h.upsample_initial_channel;
   const int Fp = (F + 3) & ~3;
   const int nk = h.num_kernels;
+  struct FlopScale {  // profiled FLOP of a ragged batch count the rows' real frames, not B x the longest row
+    Worker* w;
+    ~FlopScale() { w->flop_scale = 1.0; }
+  } fscale{w};
+  {
+    long long sum = 0;
+    for (int b = 0; b < B; ++b) sum += mel->frames[b];
+    w->flop_scale = (double)sum / ((double)B * F);
+  }
   // The nk ResBlock chains of a stage are independent (MRF).  Each chain writes its own
   // output and the average is taken by the consumer's staging load (`split_out`).  A call
   // that has the GPU to itself also runs the chains on separate streams so their workgroups
@@ -493,8 +503,9 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
 
 static int hifigan_call(mi355tts_ctx* ctx, int vocoder, const mi355tts_mel* mel, const VocCall& call) {
   if (!ctx || !mel) return fail(MI355TTS_ERR_INVALID, "null argument");
-  HifiModel* hm = nullptr;
-  CHECK(find_hifi(ctx, vocoder, &hm));
+  std::shared_ptr<HifiModel> vpin;
+  CHECK(find_hifi(ctx, vocoder, &vpin));
+  HifiModel* hm = vpin.get();
   CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), mel->B, mel->M, mel->max_frames, call));
   HIPCHECK(hipSetDevice(ctx->device));
   Worker* w = nullptr;

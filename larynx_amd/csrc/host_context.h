@@ -24,6 +24,8 @@ struct Worker {
   char* pinned_out = nullptr;  // pinned host staging for waveform outputs (grow-only)
   size_t pinned_out_bytes = 0;
   std::vector<ProfEvent> events;
+  // profiled FLOP of the launches that follow = the padded-batch figure x this (sum of the rows' real lengths / (B x longest))
+  double flop_scale = 1.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   // side streams for the independent MRF branches of a HiFi-GAN stage
   hipStream_t aux[2] = {nullptr, nullptr};
@@ -34,8 +36,8 @@ struct Worker {
 struct mi355tts_ctx {
   int device = 0;
   std::mutex mu;
-  std::map<int, std::unique_ptr<GlowModel>> glow;
-  std::map<int, std::unique_ptr<HifiModel>> hifi;
+  std::map<int, std::shared_ptr<GlowModel>> glow;
+  std::map<int, std::shared_ptr<HifiModel>> hifi;
   int next_id = 1;
   std::vector<Worker*> free_workers;
   std::vector<Worker*> all_workers;
@@ -52,6 +54,7 @@ struct mi355tts_ctx {
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;
+  size_t mel_pool_cap = 256;  // raised by mi355tts_reserve to 3 x workers + slack
   std::map<void*, size_t> mel_sizes;  // true size of every block the pool has ever handed out
   struct Acc {
     long long launches = 0;
@@ -77,6 +80,7 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
       *out = ctx->free_workers.back();
       ctx->free_workers.pop_back();
       (*out)->arena_pos = 0;
+      (*out)->flop_scale = 1.0;
       ctx->active_calls.fetch_add(1, std::memory_order_relaxed);
       return 0;
     }

@@ -23,7 +23,7 @@ struct ProfScope {
       }
     }
     ev.cls = cls;
-    ev.flop = flop;
+    ev.flop = flop * wk->flop_scale;
     hipEventRecord(ev.a, st);
   }
   ~ProfScope() {

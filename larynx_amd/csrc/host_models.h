@@ -135,9 +135,19 @@ struct GlowBlock {
   std::vector<DevConv> in, rs;
   size_t winv, an_bias, an_scale;
 };
+// Models are handed out as shared_ptr pins: a call keeps its models alive for its whole duration, mi355tts_unload only
+// drops the context's reference, and the device memory goes when the last call that uses the model has returned.
 struct GlowModel {
   mi355tts_glow_hparams hp;
+  int device = 0;
   float* arena = nullptr;
+  std::atomic<int> precision{0};  // the `half` switch (see HifiModel::precision)
+  ~GlowModel() {
+    if (arena) {
+      hipSetDevice(device);
+      hipFree(arena);
+    }
+  }
   size_t emb;
   std::vector<DevConv> pre_conv;
   std::vector<size_t> pre_g, pre_b;
@@ -162,6 +172,7 @@ struct MrfStage {
 };
 struct HifiModel {
   mi355tts_hifigan_hparams hp;
+  int device = 0;
   float* arena = nullptr;
   uint16_t* arena16 = nullptr;  // split-bf16 weight fragments of the ResBlock convs
   std::atomic<int> precision{0};  // 0 = exact f32 MFMA, 1 = split-bf16 (3 x bf16 MFMA) for the wide ResBlock convs
@@ -175,6 +186,12 @@ struct HifiModel {
   std::mutex bias_mu;
   float* bias_spec = nullptr;
   bool bias_ready = false;
+  ~HifiModel() {
+    hipSetDevice(device);
+    if (arena) hipFree(arena);
+    if (arena16) hipFree(arena16);
+    if (bias_spec) hipFree(bias_spec);
+  }
 };
 
 static std::vector<std::pair<std::string, int64_t>> glow_manifest(const mi355tts_glow_hparams& h) {

@@ -78,14 +78,7 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
     delete w;
   }
   for (auto& pe : ctx->mel_pool) hipFree(pe.first);
-  for (auto& kv : ctx->glow)
-    if (kv.second->arena) hipFree(kv.second->arena);
-  for (auto& kv : ctx->hifi) {
-    if (kv.second->arena) hipFree(kv.second->arena);
-    if (kv.second->arena16) hipFree(kv.second->arena16);
-    if (kv.second->bias_spec) hipFree(kv.second->bias_spec);
-  }
-  delete ctx;
+  delete ctx;  // the models free their device memory in their destructors
 }
 
 static int copy_name(const std::string& s, char* name, int cap) {
@@ -184,8 +177,9 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
   for (auto& kv : bl.manifest) total += kv.second;
   if (total != numel) return fail(MI355TTS_ERR_INVALID, "GlowTTS blob has %lld floats, manifest needs %lld", (long long)numel, (long long)total);
 
-  auto gm = std::make_unique<GlowModel>();
+  auto gm = std::make_shared<GlowModel>();
   gm->hp = h;
+  gm->device = ctx->device;
   ArenaBuilder ab;
   const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int k = h.kernel_size, dk = H / h.n_heads, nrel = 2 * h.window_size + 1;
@@ -350,8 +344,9 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   int64_t total = 0;
   for (auto& kv : bl.manifest) total += kv.second;
   if (total != numel) return fail(MI355TTS_ERR_INVALID, "HiFi-GAN blob has %lld floats, manifest needs %lld", (long long)numel, (long long)total);
-  auto hm = std::make_unique<HifiModel>();
+  auto hm = std::make_shared<HifiModel>();
   hm->hp = h;
+  hm->device = ctx->device;
   ArenaBuilder ab;
   std::vector<uint16_t> ab16;  // split-bf16 fragments (conv_bf16.h) of the ResBlock convs
   auto add16 = [&](DevConv& d, const float* w, int ch, int k) {
@@ -488,26 +483,28 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   return 0;
 }
 
+// Safe while other threads are synthesising with the model: every call pins its models (find_glow / find_hifi hand out
+// shared_ptr copies), so this only drops the context's reference and the id; the arenas are freed by whoever lets go
+// last — here, or the last call still using the model when it returns.  The reference frees a voice by dropping its
+// Python object the same way (larynx/__init__.py:290-300 keeps models in a dict).
 extern "C" int mi355tts_unload(mi355tts_ctx* ctx, int model) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
-  hipSetDevice(ctx->device);
-  hipDeviceSynchronize();
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  auto g = ctx->glow.find(model);
-  if (g != ctx->glow.end()) {
-    hipFree(g->second->arena);
-    ctx->glow.erase(g);
-    return 0;
+  std::shared_ptr<GlowModel> g;
+  std::shared_ptr<HifiModel> v;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto gi = ctx->glow.find(model);
+    if (gi != ctx->glow.end()) {
+      g = std::move(gi->second);
+      ctx->glow.erase(gi);
+    } else {
+      auto vi = ctx->hifi.find(model);
+      if (vi == ctx->hifi.end()) return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
+      v = std::move(vi->second);
+      ctx->hifi.erase(vi);
+    }
   }
-  auto v = ctx->hifi.find(model);
-  if (v != ctx->hifi.end()) {
-    hipFree(v->second->arena);
-    if (v->second->arena16) hipFree(v->second->arena16);
-    if (v->second->bias_spec) hipFree(v->second->bias_spec);
-    ctx->hifi.erase(v);
-    return 0;
-  }
-  return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
+  return 0;  // g / v released outside the lock (hipFree synchronises the device)
 }
 
 // §8(e): the one collective of the path.  The library does not link RCCL: the entry point is resolved from the
@@ -517,15 +514,22 @@ extern "C" int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, in
   if (!ctx || !nccl_comm || !device_blob || numel <= 0 || root < 0) return fail(MI355TTS_ERR_INVALID, "bad argument");
   typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
   typedef const char* (*errstr_fn)(int);
+  // Only the instance ALREADY loaded in this process can own the caller's communicator: RTLD_NOLOAD never maps a
+  // second copy of RCCL (handing an ncclComm_t to another instance's ncclBroadcast is undefined behaviour).
   const char* names[] = {rccl_library, "librccl.so.1", "librccl.so"};
   void* lib = nullptr;
   for (const char* n : names) {
     if (!n) continue;
-    lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // the instance that created the communicator
-    if (!lib && n == rccl_library) lib = dlopen(n, RTLD_NOW);
+    lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     if (lib) break;
   }
-  if (!lib) return fail(MI355TTS_ERR_INVALID, "RCCL library not loaded in this process (%s)", dlerror());
+  if (!lib)
+    return fail(MI355TTS_ERR_INVALID, "no RCCL library is loaded in this process under the names tried (%s, librccl.so.1, librccl.so): "
+                                      "pass the path the communicator's library was loaded from", rccl_library ? rccl_library : "-");
+  struct Close {  // RTLD_NOLOAD still takes a reference
+    void* h;
+    ~Close() { dlclose(h); }
+  } closer{lib};
   bcast_fn bcast = (bcast_fn)dlsym(lib, "ncclBroadcast");
   errstr_fn errstr = (errstr_fn)dlsym(lib, "ncclGetErrorString");
   if (!bcast) return fail(MI355TTS_ERR_INVALID, "ncclBroadcast not found in the RCCL library");
@@ -583,14 +587,16 @@ static void* pool_alloc(mi355tts_ctx* ctx, size_t bytes) {
 }
 static void pool_free(mi355tts_ctx* ctx, void* p, size_t /*requested*/) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  const size_t bytes = ctx->mel_sizes[p];  // the block's true size, not the size last asked for
-  if (ctx->mel_pool.size() < 256) {
-    ctx->mel_pool.emplace_back(p, bytes);
-    return;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->mel_sizes.find(p);  // the block's true size, not the size last asked for
+    if (it != ctx->mel_sizes.end() && ctx->mel_pool.size() < ctx->mel_pool_cap) {
+      ctx->mel_pool.emplace_back(p, it->second);
+      return;
+    }
+    if (it != ctx->mel_sizes.end()) ctx->mel_sizes.erase(it);
   }
-  ctx->mel_sizes.erase(p);
-  hipFree(p);
+  hipFree(p);  // over the cap, or a pointer the pool never handed out
 }
 static size_t mel_bytes(const mi355tts_mel* m) { return (size_t)m->B * m->M * (size_t)std::max(m->ld, 1) * sizeof(float); }
 static void mel_destroy(mi355tts_mel* m) {
@@ -703,10 +709,12 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
                                    int32_t pad_before, int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16,
                                    int64_t wav_ld, uint32_t flags) {
   if (!ctx || !frames_out) return fail(MI355TTS_ERR_INVALID, "null argument");
-  const GlowModel* gm = nullptr;
-  HifiModel* hm = nullptr;
-  CHECK(find_glow(ctx, glow, &gm));
-  CHECK(find_hifi(ctx, vocoder, &hm));
+  std::shared_ptr<GlowModel> gpin;
+  std::shared_ptr<HifiModel> vpin;
+  CHECK(find_glow(ctx, glow, &gpin));
+  CHECK(find_hifi(ctx, vocoder, &vpin));
+  const GlowModel* gm = gpin.get();
+  HifiModel* hm = vpin.get();
   GlowCall g;
   g.ids = ids;
   g.id_lens = id_lens;
@@ -757,10 +765,12 @@ extern "C" int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vo
                                 int max_frames, int denoiser, int max_pad_samples) {
   if (!ctx || workers < 1 || workers > 256 || max_batch < 1 || max_ids < 1 || max_frames < 1 || max_pad_samples < 0)
     return fail(MI355TTS_ERR_INVALID, "bad argument");
-  const GlowModel* gm = nullptr;
-  HifiModel* hm = nullptr;
-  if (glow > 0) CHECK(find_glow(ctx, glow, &gm));
-  if (vocoder > 0) CHECK(find_hifi(ctx, vocoder, &hm));
+  std::shared_ptr<GlowModel> gpin;
+  std::shared_ptr<HifiModel> vpin;
+  if (glow > 0) CHECK(find_glow(ctx, glow, &gpin));
+  if (vocoder > 0) CHECK(find_hifi(ctx, vocoder, &vpin));
+  const GlowModel* gm = gpin.get();
+  HifiModel* hm = vpin.get();
   if (gm && max_frames % gm->hp.n_sqz) max_frames += gm->hp.n_sqz - max_frames % gm->hp.n_sqz;
   size_t need = 0, mel_bytes = 0;
   int M = 0;
@@ -803,7 +813,11 @@ extern "C" int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vo
   }
   for (Worker* w : held) release_worker(ctx, w);
   if (rc) return rc;
-  // result blocks: per in-flight call two mel planes + one frame-count block
+  // result blocks: per in-flight call two mel planes + one frame-count block (the pool must be able to hold them all)
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->mel_pool_cap = std::max(ctx->mel_pool_cap, (size_t)3 * workers + 64);
+  }
   if (mel_bytes) {
     std::vector<void*> blocks;
     for (int i = 0; i < workers && !rc; ++i) {

@@ -70,24 +70,26 @@ struct MrfArgs {
 //   src  : LDS source ([C][W], lrelu already applied)
 //   boff : per slot, (lane >> 4) * W + 16 * block + (lane & 15)  (the B element of tap offset 0, channel quad 0)
 //   t0   : tap 0's column offset (-pad);  taps are `dil` columns apart
-template <int C, int W, int NB, int NS>
+template <int C, int W, int NB, int NS, int CORE, int NW>
 __device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], float (&an)[C / 4], const float* __restrict__ wp,
-                                              const float* __restrict__ src, const int (&boff)[NS], const int t0, const int dil, const int K) {
+                                              const float* __restrict__ src, const int core_off, const int (&halo_off)[NS - CORE],
+                                              const int t0, const int dil, const int K) {
   constexpr int CQ = C / 4;
   // One step = one (tap, channel quad) = NB MFMAs, one per slot.  Software pipeline, written out: the B operands of
   // the next step (NB ds_read_b32) and the A fragment of the same quad one tap ahead (one global load) are requested
   // in the shadow of this step's MFMAs — one request pinned behind each MFMA — and nothing moves across a step
   // boundary, which bounds the live registers to two steps' operands.  The tap loop is a real loop (K is a run-time
-  // value): unrolled over (K, NB) the kernel was ~100 KB of straight-line code for a 64 KB instruction cache that
-  // two CUs share.  On the last tap the prefetches read one tap too far: the next conv's fragments (inside the
-  // weight arena) and columns inside the LDS slack — values nothing uses.
-  int bo[NB];
+  // value): unrolled over (K, NB) the kernel was ~100 KB of straight-line code.  On the last tap the prefetches read
+  // one tap too far: the next conv's fragments (inside the weight arena) and columns inside the LDS slack — values
+  // nothing uses.  The core slots of a wave are 16*NW columns apart: ONE address register + immediate offsets.
+  const float* pc = src + core_off + t0;  // core slot s reads pc[s * 16 * NW + q * 4 * W]
+  const float* ph[NS - CORE];
+#pragma unroll
+  for (int h = 0; h < NS - CORE; ++h) ph[h] = src + halo_off[h] + t0;
+  auto bread = [&](int s, int q) -> float { return s < CORE ? pc[s * 16 * NW + q * 4 * W] : ph[s - CORE][q * 4 * W]; };
   float bcur[NB], bnxt[NB];
 #pragma unroll
-  for (int s = 0; s < NB; ++s) {
-    bo[s] = boff[s] + t0;
-    bcur[s] = src[bo[s]];
-  }
+  for (int s = 0; s < NB; ++s) bcur[s] = bread(s, 0);
   const float* wt = wp + CQ * 64;  // the next tap's fragments
   const int taps = ((MRF_ABL & 32) && dil < 99) ? 0 : K;
 #pragma unroll 1
@@ -104,12 +106,13 @@ __device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], float (&an)[C 
         for (int s = 0; s < NB; ++s) bnxt[s] = bcur[s] + 1.0f;
       } else if (q + 1 < CQ) {
 #pragma unroll
-        for (int s = 0; s < NB; ++s) bnxt[s] = src[bo[s] + (q + 1) * 4 * W];
+        for (int s = 0; s < NB; ++s) bnxt[s] = bread(s, q + 1);
       } else {
+        pc += dil;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) bo[s] += dil;
+        for (int h = 0; h < NS - CORE; ++h) ph[h] += dil;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) bnxt[s] = src[bo[s]];
+        for (int s = 0; s < NB; ++s) bnxt[s] = bread(s, 0);
       }
 #pragma unroll
       for (int s = 0; s < NB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[s], acc[s], 0, 0, 0);
@@ -184,29 +187,28 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
   const float slope = a.slope;
   const float* xb = a.x + (long long)b * a.bs;
 
-  // ---- this wave's slots: core blocks first, then its halo blocks, nearest to the core first
-  // halo entry e = wave + NW*h: even -> left block 3 - e/2, odd -> right block 4 + T/16 + e/2
+  // ---- this wave's slots: CORE core blocks (16*NW columns apart, from block 4 + wave), then its halo blocks, nearest
+  // to the core first: halo entry e = wave + NW*h: even -> left block 3 - e/2, odd -> right block 4 + T/16 + e/2.
+  // A lane owns, in the C/D layout, rows 4*rq + r (r = 0..3) of column col_of(s) of each slot.
   const int colq = lane & 15, rq = lane >> 4;
-  int blk[NS];
-#pragma unroll
-  for (int s = 0; s < CORE; ++s) blk[s] = MRF_HALO / 16 + wave + NW * s;
+  const int core_col = 16 * (MRF_HALO / 16 + wave) + colq;
+  int halo_col[HS];
 #pragma unroll
   for (int h = 0; h < HS; ++h) {
     const int e = wave + NW * h;
-    blk[CORE + h] = (e & 1) ? (MRF_HALO / 16 + T / 16 + (e >> 1)) : (MRF_HALO / 16 - 1 - (e >> 1));
+    halo_col[h] = 16 * ((e & 1) ? (MRF_HALO / 16 + T / 16 + (e >> 1)) : (MRF_HALO / 16 - 1 - (e >> 1))) + colq;
   }
-  int boff[NS];
+  auto col_of = [&](int s) -> int { return s < CORE ? core_col + 16 * NW * s : halo_col[s - CORE]; };
+  const int core_off = rq * W + core_col;  // B element (tap offset 0, channel quad 0) of core slot 0
+  int halo_off[HS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) boff[s] = rq * W + 16 * blk[s] + colq;
-  // positions this lane owns in the C/D layout: rows 4*rq + r (r = 0..3), column 16*blk[s] + colq
+  for (int h = 0; h < HS; ++h) halo_off[h] = rq * W + halo_col[h];
   const int row0 = 4 * rq;
   const bool rows_ok = row0 < C;  // C = 8: the upper half of the MFMA block is padding
-  bool inside[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int g = gx0 + 16 * blk[s] + colq;
-    inside[s] = g >= 0 && g < L;
-  }
+  auto inside = [&](int s) -> bool {  // the slot's column lies inside the sequence
+    const int g = gx0 + col_of(s);
+    return g >= 0 && g < L;
+  };
 
   floatx4 sum[CORE];
   floatx4 xres[NS];
@@ -230,13 +232,6 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
       pre[i] = *reinterpret_cast<const float4*>(xb + (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int g = gx0 + 16 * blk[s] + colq;
-      const float* xp = xb + (inside[s] ? g : 0) + (rows_ok ? row0 : 0) * a.ld;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xres[s][r] = xp[r * a.ld];
-    }
-#pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int e = tid + NT * i;
       const int row = e / F4, f = e - row * F4;
@@ -252,10 +247,17 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
       v.w = v.w > 0.f ? v.w : v.w * slope;
       if (e < NF4) *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
     }
+    // (after the tile is in LDS: its staging registers are dead by now; first needed at the first conv2's epilogue)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float* xp = xb + (inside(s) ? gx0 + col_of(s) : 0) + (rows_ok ? row0 : 0) * a.ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[s][r] = xp[r * a.ld];
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xres[s][r] = (inside[s] && rows_ok) ? xres[s][r] : 0.f;
+      for (int r = 0; r < 4; ++r) xres[s][r] = (inside(s) && rows_ok) ? xres[s][r] : 0.f;
   };
   auto prefetch = [&](int chain, int step, int cv) __attribute__((always_inline)) {  // tap 0's fragments and the bias of conv (chain, step, cv)
     const float* wp = a.w + a.tab[(chain * MRF_MAX_STEPS + step) * 2 + cv] + lane;
@@ -297,9 +299,9 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = floatx4{bb[0], bb[1], bb[2], bb[3]};
         // wave-uniform slot count -> one instantiation of the MFMA loop per count
-        if (HS >= 2 && nh >= 2) mrf_conv_taps<C, W, (HS >= 2 ? CORE + 2 : NS), NS>(acc, an, wp, src, boff, -P2 * d, d, K);
-        else if (nh >= 1) mrf_conv_taps<C, W, CORE + 1, NS>(acc, an, wp, src, boff, -P2 * d, d, K);
-        else mrf_conv_taps<C, W, CORE, NS>(acc, an, wp, src, boff, -P2 * d, d, K);
+        if (HS >= 2 && nh >= 2) mrf_conv_taps<C, W, (HS >= 2 ? CORE + 2 : NS), NS, CORE, NW>(acc, an, wp, src, core_off, halo_off, -P2 * d, d, K);
+        else if (nh >= 1) mrf_conv_taps<C, W, CORE + 1, NS, CORE, NW>(acc, an, wp, src, core_off, halo_off, -P2 * d, d, K);
+        else mrf_conv_taps<C, W, CORE, NS, CORE, NW>(acc, an, wp, src, core_off, halo_off, -P2 * d, d, K);
         const int nb = CORE + nh;
         // the next conv's first weights + bias go out before this epilogue
         if (cv == 0) prefetch(chain, step, 1);
@@ -310,11 +312,13 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
             if (s < nb && rows_ok) {
+              const bool in = inside(s);
+              float* tp = TB + row0 * W + col_of(s);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 float v = acc[s][r];
                 v = v > 0.f ? v : v * slope;
-                if (!(MRF_ABL & 4) || a.nsteps == 99) TB[(row0 + r) * W + 16 * blk[s] + colq] = inside[s] ? v : 0.f;
+                if (!(MRF_ABL & 4) || a.nsteps == 99) tp[r * W] = in ? v : 0.f;
               }
             }
           }
@@ -323,11 +327,13 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
             if (s < nb) {
+              const bool in = inside(s);
+              float* xp = XL + row0 * W + col_of(s);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float v = inside[s] ? acc[s][r] + xres[s][r] : 0.f;
+                const float v = in ? acc[s][r] + xres[s][r] : 0.f;
                 xres[s][r] = v;
-                if (!last && rows_ok && (!(MRF_ABL & 4) || a.nsteps == 99)) XL[(row0 + r) * W + 16 * blk[s] + colq] = v > 0.f ? v : v * slope;
+                if (!last && rows_ok && (!(MRF_ABL & 4) || a.nsteps == 99)) xp[r * W] = v > 0.f ? v : v * slope;
               }
             }
           }
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
     float* yb = (part == 0 ? a.y2 : a.y) + (long long)b * a.bs;
 #pragma unroll
     for (int s = 0; s < CORE; ++s) {
-      const int g = gx0 + 16 * blk[s] + colq;
+      const int g = gx0 + col_of(s);
       if (g < L) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) yb[(long long)(row0 + r) * a.ld + g] = sum[s][r];

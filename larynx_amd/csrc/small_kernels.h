@@ -435,20 +435,24 @@ __global__ void duration_kernel(const float* logw, long long bs, const int* len,
   const float* lw = logw + (long long)b * bs;
   const float capf = (float)max_frames_cap;  // <= 2^28: two capped terms still fit an int
   auto dur = [&](int t) { return (int)fminf(fmaxf(ceilf(expf(lw[t]) * length_scale), 0.f), capf); };
-  int run = 0;
-  for (int t = t0; t < t1; ++t) run = min(run + dur(t), max_frames_cap);
-  int incl = run;
+  // the scan runs UNCLAMPED in 64 bits (exact for any input: <= 2^28 per id) and only what is written is capped, so
+  // cum[] stays monotone also when the sum overflows the cap (the call then fails with NOMEM on the host side)
+  long long run = 0;
+  for (int t = t0; t < t1; ++t) run += dur(t);
+  long long incl = run;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(incl, d);
-    if (lane >= d) incl = min(incl + o, max_frames_cap);
+    const unsigned lo = __shfl_up((unsigned)(incl & 0xffffffffLL), d), hi = __shfl_up((unsigned)(incl >> 32), d);
+    const long long o = ((long long)hi << 32) | (long long)lo;
+    if (lane >= d) incl += o;
   }
-  int acc = incl - run;  // exclusive prefix of this lane's run
+  long long acc = incl - run;  // exclusive prefix of this lane's run
   for (int t = t0; t < t1; ++t) {
-    acc = min(acc + dur(t), max_frames_cap);
-    cum[(long long)b * cum_ld + t] = acc;
+    acc += dur(t);
+    cum[(long long)b * cum_ld + t] = (int)(acc < (long long)max_frames_cap ? acc : (long long)max_frames_cap);
   }
-  const int total = __shfl(incl, 63);
+  const long long total64 = ((long long)__shfl((unsigned)(incl >> 32), 63) << 32) | (long long)__shfl((unsigned)(incl & 0xffffffffLL), 63);
+  const int total = (int)(total64 < (long long)max_frames_cap ? total64 : (long long)max_frames_cap);
   if (lane == 0) {
     int y = total > 1 ? total : 1;
     y = (y / n_sqz) * n_sqz;
@@ -472,11 +476,12 @@ __device__ __forceinline__ float gauss_noise(uint64_t seed, uint32_t b, uint32_t
   return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
 }
 
-// The generator alone, out[b][c][t] = gauss_noise(seed, b, c, t): what the distribution tests look at.
+// The generator alone, out[b][c][t] = the draw of row stream seed + b (as expand_noise_squeeze_kernel keys it): what the
+// distribution tests look at.
 __global__ void noise_fill_kernel(float* out, int C, int T, uint64_t seed) {
   const int b = blockIdx.z, c = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < T) out[((long long)b * C + c) * T + t] = gauss_noise(seed, (uint32_t)b, (uint32_t)c, (uint32_t)t);
+  if (t < T) out[((long long)b * C + c) * T + t] = gauss_noise(seed + (uint64_t)b, 0u, (uint32_t)c, (uint32_t)t);
 }
 
 // G9b+G10+G11: frame j of row b repeats id idx(j) = #{t : cum[t] <= j}
@@ -486,8 +491,11 @@ __global__ void noise_fill_kernel(float* out, int C, int T, uint64_t seed) {
 __global__ void expand_noise_squeeze_kernel(const float* xm, long long xm_bs, int xm_ld, const int* len,
                                             const int* cum, int cum_ld, const int* frames, const float* noise,
                                             long long noise_bs, int noise_ld, float noise_scale, uint64_t seed,
-                                            int M, int n_sqz, float* z, long long z_bs, int z_ld) {
+                                            const unsigned long long* row_seeds, int M, int n_sqz, float* z, long long z_bs, int z_ld) {
   const int b = blockIdx.z;
+  // the noise stream of a row is keyed by the ROW's seed (row_seeds[b], default seed + b) and nothing else: an
+  // utterance draws the same field in a batch as in a call of its own with that seed
+  const uint64_t rseed = row_seeds ? (uint64_t)row_seeds[b] : seed + (uint64_t)b;
   const int F = frames[b];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= F) return;
@@ -504,7 +512,7 @@ __global__ void expand_noise_squeeze_kernel(const float* xm, long long xm_bs, in
     float v = xm[(long long)b * xm_bs + (long long)c * xm_ld + id];
     if (noise_scale != 0.f) {
       const float nz = noise ? noise[(long long)b * noise_bs + (long long)c * noise_ld + j]
-                             : gauss_noise(seed, (uint32_t)b, (uint32_t)c, (uint32_t)j);
+                             : gauss_noise(rseed, 0u, (uint32_t)c, (uint32_t)j);
       v += nz * noise_scale;
     }
     z[(long long)b * z_bs + (long long)(s * M + c) * z_ld + j2] = v;

@@ -151,10 +151,12 @@ class Engine:
         noise: typing.Optional[np.ndarray] = None,
         seed: int = 0,
         audio_settings=None,
+        row_seeds: typing.Optional[typing.Sequence[int]] = None,
     ) -> MelBatch:
         """`ids`: one int64 vector [P] or a list of them (variable length batch).
         `noise`: optional [B, M, >=F] (or [M, >=F] for B=1) standing in for the
-        reference's `torch.randn_like` draw."""
+        reference's `torch.randn_like` draw.  Without it the device generator draws: row b from
+        the stream `row_seeds[b]` (default `seed + b`) — the field a batch-1 call with that seed draws."""
         rows = [np.asarray(ids, np.int64)] if isinstance(ids, np.ndarray) and ids.ndim == 1 else [np.asarray(r, np.int64) for r in ids]
         if isinstance(ids, np.ndarray) and ids.ndim == 2:
             rows = [np.asarray(r, np.int64) for r in ids]
@@ -174,6 +176,19 @@ class Engine:
             nz_ptr, nz_ld = noise.ctypes.data, noise.shape[2]
         a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
         out = C.c_void_p()
+        if row_seeds is not None:
+            if noise is not None or len(row_seeds) != B:
+                raise ValueError("row_seeds: one seed per row, and no explicit noise")
+            rs = np.array([int(x) & (2 ** 64 - 1) for x in row_seeds], np.uint64)
+            ffi.check(
+                self.lib,
+                self.lib.mi355tts_glow_infer_rows(
+                    self._ctx, model, packed.ctypes.data, lens.ctypes.data_as(C.POINTER(C.c_int32)), B, packed.shape[1],
+                    float(noise_scale), float(length_scale), rs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                    C.byref(a) if a is not None else None, 0, C.byref(out),
+                ),
+            )
+            return MelBatch(self, out.value)
         ffi.check(
             self.lib,
             self.lib.mi355tts_glow_infer(

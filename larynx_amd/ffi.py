@@ -89,6 +89,11 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
     "mi355tts_unload": (C.c_int, [_VP, C.c_int]),
     "mi355tts_model_set_precision": (C.c_int, [_VP, C.c_int, C.c_int]),
     "mi355tts_broadcast_weights": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int64, C.c_char_p]),
+    "mi355tts_glow_infer_rows": (
+        C.c_int,
+        [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64),
+         C.POINTER(AudioSettingsC), C.c_uint32, C.POINTER(_VP)],
+    ),
     "mi355tts_glow_infer": (
         C.c_int,
         [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,

@@ -74,6 +74,7 @@ def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
     b = bytes(buf)
     dims: typing.List[int] = []
     dtype, name, raw = 1, "", None
+    external = False
     floats: typing.List[float] = []
     ints: typing.List[int] = []
     doubles: typing.List[float] = []
@@ -92,8 +93,18 @@ def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
             raw = bytes(v)
         elif f == 10:
             doubles += list(struct.unpack(f"<{len(v) // 8}d", bytes(v))) if w == 2 else [struct.unpack("<d", v)[0]]
+        elif f == 13:  # external_data entries
+            external = True
+        elif f == 14:  # data_location: 1 = EXTERNAL
+            external = external or v == 1
     if dtype not in _DTYPES:
         raise ValueError(f"tensor '{name}': unsupported ONNX data type {dtype}")
+    if external and raw is None:
+        raise ValueError(f"tensor '{name}': its data lives in an external file (data_location = EXTERNAL), which this reader "
+                         "does not follow — re-export the model with the weights embedded")
+    if dtype == 10 and raw is None and ints:
+        # float16 values in int32_data are BIT PATTERNS (onnx.proto: "float16 values must be bit-wise converted to an uint16_t")
+        raw = np.asarray(ints, np.uint16).tobytes()
     np_t = _DTYPES[dtype]
     if raw is not None:
         arr = np.frombuffer(raw, dtype=np.dtype(np_t).newbyteorder("<")).astype(np_t)
@@ -104,7 +115,10 @@ def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
     else:
         arr = np.asarray(ints, np_t)
     shape = tuple(int(d) for d in dims)
-    return name, arr.reshape(shape) if arr.size == int(np.prod(shape, dtype=np.int64)) else arr
+    want = int(np.prod(shape, dtype=np.int64))
+    if arr.size != want:
+        raise ValueError(f"tensor '{name}': {arr.size} elements stored for dims {list(shape)} ({want} expected)")
+    return name, arr.reshape(shape)
 
 
 class Node(typing.NamedTuple):

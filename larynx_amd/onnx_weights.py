@@ -156,6 +156,27 @@ def state_dict_from_onnx(path: typing.Union[str, Path], manifest_names: typing.S
                     an_pairs.append((np.asarray(c[1]), logs.astype(np.float32)))
                     break
 
+    def anchor_size(norm_name: str) -> typing.Optional[int]:
+        """Channels the folded tensor `norm_name` must have: the rows of the named conv its layer follows (a structural
+        anchor on top of the execution-order matching: an extra or displaced [1, C, 1] Mul -> Add pair of another width
+        fails here instead of loading as garbage)."""
+        import re
+
+        for pat, conv in ((r"(.*\.pre)\.norm_layers\.(\d+)\.", r"\1.conv_layers.\2.bias"),
+                          (r"(.*)\.norm_layers_1\.(\d+)\.", r"\1.attn_layers.\2.conv_o.bias"),
+                          (r"(.*)\.norm_layers_2\.(\d+)\.", r"\1.ffn_layers.\2.conv_2.bias"),
+                          (r"(.*\.proj_w)\.norm_(\d+)\.", r"\1.conv_\2.bias")):
+            m = re.match(pat, norm_name)
+            if m:
+                b = named.get(m.expand(conv))
+                return int(np.asarray(b).size) if b is not None else None
+        m = re.match(r"(decoder\.flows)\.(\d+)\.(logs|bias)$", norm_name)
+        if m:  # ActNorm of block b sits two flows before that block's coupling layer, whose `end` conv has as many rows
+            b = named.get(f"{m.group(1)}.{int(m.group(2)) + 2}.end.bias")
+            return int(np.asarray(b).size) if b is not None else None
+        return None
+
+    recovered: typing.List[str] = []
     need_inv = [m for m in missing if m.endswith(".weight_inv")]
     need_gamma = [m for m in missing if m.endswith(".gamma")]
     need_beta = [m for m in missing if m.endswith(".beta")]
@@ -171,6 +192,7 @@ def state_dict_from_onnx(path: typing.Union[str, Path], manifest_names: typing.S
             raise KeyError(f"{path}: {len(inv_weights)} {n_split}x{n_split} convs in the graph, {len(blocks)} InvConvNear weights needed")
         for name, w in zip(reversed(blocks), inv_weights):
             out[name] = w.reshape(n_split, n_split)
+            recovered.append(name)
     if need_gamma or need_beta:
         if len(need_gamma) != len(need_beta) or len(ln_pairs) < len(need_gamma):
             raise KeyError(f"{path}: {len(ln_pairs)} LayerNorm scale/shift pairs in the graph, {len(need_gamma)} needed")
@@ -178,17 +200,33 @@ def state_dict_from_onnx(path: typing.Union[str, Path], manifest_names: typing.S
         if len(ln_pairs) != len(all_ln):
             raise KeyError(f"{path}: {len(ln_pairs)} LayerNorm patterns, model has {len(all_ln)} LayerNorms")
         for k, gname in enumerate(all_ln):
+            want = anchor_size(gname)
+            if want is not None and ln_pairs[k][0].size != want:
+                raise KeyError(f"{path}: LayerNorm pattern #{k} has {ln_pairs[k][0].size} channels but '{gname}' follows a conv of "
+                               f"{want}: the graph's Mul/Add order does not match the model (exporter layout not recognised)")
             if gname in need_gamma:
                 out[gname] = ln_pairs[k][0].reshape(-1)
                 out[gname[: -len("gamma")] + "beta"] = ln_pairs[k][1].reshape(-1)
+                recovered += [gname, gname[: -len("gamma")] + "beta"]
     if need_logs:
         all_an = sorted([m for m in manifest_names if m.endswith(".logs")], key=lambda s: int(s.split(".")[2]))
         if len(an_pairs) != len(all_an):
             raise KeyError(f"{path}: {len(an_pairs)} ActNorm patterns in the graph, model has {len(all_an)}")
         for lname, (bias, logs) in zip(reversed(all_an), an_pairs):
+            want = anchor_size(lname)
+            if want is not None and logs.size != want:
+                raise KeyError(f"{path}: ActNorm pattern for '{lname}' has {logs.size} channels, its coupling block has {want} "
+                               "(exporter layout not recognised)")
             if lname in need_logs:
+                recovered.append(lname)
                 out[lname] = logs.reshape(1, -1, 1)
                 bname = lname[: -len("logs")] + "bias"
                 if bname not in out:
                     out[bname] = bias.reshape(1, -1, 1)
+                    recovered.append(bname)
+    if recovered:
+        import logging
+
+        logging.getLogger("larynx_amd.onnx").info("%s: %d tensors had lost their names to constant folding and were recovered by graph "
+                                                  "pattern, in execution order: %s", path, len(recovered), ", ".join(recovered))
     return out

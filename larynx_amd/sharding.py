@@ -82,19 +82,17 @@ def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[n
                      batch: int = 1) -> typing.Dict[int, np.ndarray]:
     """This rank's share of the work list -> {utterance index: int16 audio}.
     `batch` > 1 runs length-bucketed micro-batches through one pair of calls each.  The
-    kernels mask by row length, so with `noise_scale == 0` (or explicit noise) every row equals
-    its own batch-1 result; the device RNG is keyed by (call seed, row, channel, frame), so with
-    `noise_scale != 0` a row of a micro-batch draws a different — equally distributed — noise
-    field than the same utterance would in a call of its own."""
+    kernels mask by row length and the device RNG stream of a row is keyed by the UTTERANCE
+    (`seed + utterance index`, `mi355tts_glow_infer_rows`), so every utterance gets the audio a
+    call of its own would give it — whatever rank it lands on and whatever batch it rides in."""
     lengths = [len(r) for r in id_rows]
     mine = lpt_assign(lengths, world)[rank]
     out: typing.Dict[int, np.ndarray] = {}
     hop = engine.hop(vocoder)
     for group in micro_batches(mine, lengths, batch):
         rows = [np.asarray(id_rows[i], np.int64) for i in group]
-        # device RNG streams are keyed by (seed, row, channel, frame): give each call its own seed
         mel = engine.glow_infer(glow, rows if len(rows) > 1 else rows[0], noise_scale, length_scale,
-                                seed=seed + group[0], audio_settings=audio_settings)
+                                row_seeds=[seed + i for i in group], audio_settings=audio_settings)
         _, i16 = engine.hifigan_infer(vocoder, mel, want_float=False)
         for b, i in enumerate(group):
             out[i] = i16[b, : int(mel.frames[b]) * hop].copy()

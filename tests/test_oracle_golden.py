@@ -75,6 +75,30 @@ def test_torch_operator_port_matches_numpy_oracle():
         assert np.sqrt(np.mean((a - b) ** 2)) < 2e-6
 
 
+def test_torch_glow_port_matches_numpy_oracle_and_the_reference_golden():
+    """The GlowTTS half of bench.py's cpu_baseline (oracle/glow_tts_torch.py: torch CPU operators, the arithmetic of the
+    reference's `--backend pytorch`) is the same function as the numpy oracle — and reproduces a golden mel the
+    reference's own modules produced."""
+    pytest.importorskip("torch")
+    from larynx_amd import hparams as HP
+    from oracle import glow_tts_torch
+    from tests.golden_util import load_case
+
+    hp = HP.TINY_GLOW
+    sd = synthetic.make_glow_state_dict(hp, seed=5)
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(3), 23, hp.num_symbols)
+    noise = np.random.default_rng(1).standard_normal((hp.mel_channels, 16 * 23 + 64)).astype(np.float32)
+    for ns, ls in ((0.667, 1.0), (0.0, 1.3)):
+        a = glow_tts_np.glow_tts_infer(sd, hp, ids, noise, ns, ls)
+        b = glow_tts_torch.glow_tts_infer_torch(sd, hp, ids, noise, ns, ls)
+        assert a.shape == b.shape and np.abs(a - b).max() < 5e-6
+    c = load_case("ljspeech_high_short5")
+    gsd = synthetic.make_glow_state_dict(c["glow_hp"], seed=1234)
+    mel = glow_tts_torch.glow_tts_infer_torch(gsd, c["glow_hp"], c["ids"], c["noise"], float(c["noise_scale"]), float(c["length_scale"]))
+    assert mel.shape == c["mel"].shape
+    np.testing.assert_allclose(mel, c["mel"], atol=2e-5)
+
+
 def test_oracle_reproduces_config4_batch_rows():
     """BASELINE config 4 golden (thorsten + 'medium', 8 rows, each through the reference at
     B = 1): the oracle on the three shortest rows, GlowTTS and vocoder."""

@@ -46,6 +46,17 @@ def test_micro_batched_shard_equals_single_calls(emu_engine):
     for i in range(5):
         assert one[i].shape == many[i].shape
         assert np.abs(one[i].astype(np.int32) - many[i].astype(np.int32)).max() <= 1
+    # with the device noise generator ON: a row's stream is keyed by the utterance (seed + index), so the micro-batched
+    # shard still reproduces the single calls — and a direct batch-1 call with that seed gives the same audio
+    one = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=40)
+    many = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=40, batch=3)
+    quiet = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.0)
+    for i in range(5):
+        assert np.abs(one[i].astype(np.int32) - many[i].astype(np.int32)).max() <= 1
+        assert not np.array_equal(one[i], quiet[i])  # the noise really is on
+    mel = emu_engine.glow_infer(g, rows[3], 0.667, 1.0, seed=43)
+    _, direct = emu_engine.hifigan_infer(v, mel, want_float=False)
+    assert np.abs(direct[0, : one[3].shape[0]].astype(np.int32) - one[3].astype(np.int32)).max() <= 1
 
 
 def _worker(rank, world, port, lib, out_dir):

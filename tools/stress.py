@@ -32,13 +32,82 @@ def vram_used():
         return -1
 
 
+def unload_leg(eng, threads: int, seconds: float):
+    """A voice is unloaded and reloaded (and the schedule options are flipped) WHILE `threads` host threads synthesise with
+    it: calls that already hold the model finish with the right audio (models are pinned per call), calls that arrive
+    after the unload fail cleanly with MI355TTS_ERR_NO_MODEL, nothing crashes, and VRAM use returns to where it was."""
+    import threading
+
+    from larynx_amd import ffi
+
+    s = ljspeech_audio_settings()
+    ghp, vhp = HP.LJSPEECH, HP.HIFIGAN_MEDIUM
+    gsd = synthetic.make_glow_state_dict(ghp, seed=1234)
+    vsd = synthetic.make_hifigan_state_dict(vhp, seed=1234)
+    rng = np.random.default_rng(5)
+    rows = [synthetic.synthetic_phoneme_ids(rng, int(n), ghp.num_symbols) for n in rng.integers(10, 120, 12)]
+    g0, v0 = eng.load_glow(ghp, gsd), eng.load_hifigan(vhp, vsd)
+    want = [eng.synthesize(g0, v0, r, 0.667, 0.8, seed=k, audio_settings=s)[2] for k, r in enumerate(rows)]
+    ids = {"g": g0, "v": v0}
+    stop = threading.Event()
+    stats = {"ok": 0, "no_model": 0, "bad": 0}
+    lock = threading.Lock()
+
+    def worker(t):
+        k = t
+        while not stop.is_set():
+            k = (k + 1) % len(rows)
+            try:
+                i16 = eng.synthesize(ids["g"], ids["v"], rows[k], 0.667, 0.8, seed=k, audio_settings=s)[2]
+                good = np.array_equal(i16, want[k])
+                with lock:
+                    stats["ok" if good else "bad"] += 1
+            except ffi.Mi355ttsError as e:
+                with lock:
+                    stats["no_model" if e.code == -5 else "bad"] += 1  # MI355TTS_ERR_NO_MODEL: looked the id up after the unload
+
+    used0 = vram_used()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for t in th:
+        t.start()
+    t_end = time.perf_counter() + seconds
+    cycles = 0
+    while time.perf_counter() < t_end:
+        time.sleep(0.02)
+        old_g, old_v = ids["g"], ids["v"]
+        eng.unload(old_g)  # in-flight calls keep their pin; new ones fail with NO_MODEL until the reload below
+        eng.set_option("mrf_group", cycles % 2)
+        eng.set_option("mrf_small", (cycles // 2) % 2)
+        time.sleep(0.005)
+        ids["g"] = eng.load_glow(ghp, gsd)
+        eng.unload(old_v)
+        ids["v"] = eng.load_hifigan(vhp, vsd)
+        cycles += 1
+    stop.set()
+    for t in th:
+        t.join()
+    eng.set_option("mrf_group", 1)
+    eng.set_option("mrf_small", 1)
+    eng.unload(ids["g"])
+    eng.unload(ids["v"])
+    used1 = vram_used()
+    assert stats["bad"] == 0 and stats["ok"] > 0, stats
+    return {"unload_reload_cycles": cycles, "threads": threads, **stats, "vram_delta_bytes": used1 - used0}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--unload-leg", type=float, default=0.0, metavar="SECONDS",
+                    help="only the unload/reload-under-load leg, for this long (6 threads unless --threads is given)")
     ap.add_argument("--calls", type=int, default=1500)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--no-reserve", action="store_true", help="leave the workspaces grow-only (no mi355tts_reserve up front)")
     args = ap.parse_args()
     eng = Engine(0)
+    if args.unload_leg > 0:
+        print(json.dumps(unload_leg(eng, args.threads if args.threads != 4 else 6, args.unload_leg)))
+        eng.close()
+        return
     s = ljspeech_audio_settings()
     from larynx_amd import ffi
 
