@@ -131,6 +131,15 @@ __device__ __forceinline__ void mrf_conv_taps(floatx4 (&acc)[NS], float (&an)[C 
   }
 }
 
+// A value the optimiser must treat as new (wave-uniform ints): the second chain of a workgroup recomputes its staging
+// addresses instead of keeping the first chain's six 64-bit pointers alive — spilled to scratch — through a whole chain.
+__device__ __forceinline__ int mrf_opaque(int v) {
+#if defined(__AMDGCN__)
+  asm volatile("" : "+s"(v));
+#endif
+  return v;
+}
+
 template <int C, int T, int NW>
 struct MrfGeom {
   static constexpr int W = T + 2 * MRF_HALO + 16;  // LDS row stride: = 16 (mod 32) floats -> B reads of 4 rows x 16 columns hit 64 distinct banks
@@ -210,7 +219,6 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
     return g >= 0 && g < L;
   };
 
-  floatx4 sum[CORE];
   floatx4 xres[NS];
   floatx4 acc[NS];
   float an[CQ];  // tap 0's A fragments of the NEXT conv, requested one epilogue ahead
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
 
   // chain start: XL = lrelu(x) for the whole tile (16-byte loads, branch-free, zero outside the sequence) and the raw
   // residual stream of the owned positions straight from global memory (L2-hot: the tile was just read)
-  auto stage = [&]() __attribute__((always_inline)) {
+  auto stage = [&](const int gx0) __attribute__((always_inline)) {  // (shadows gx0 with the caller's — possibly laundered — copy)
     constexpr int F4 = G::NCOL / 4;
     constexpr int NF4 = C * F4;
     constexpr int NE = (NF4 + NT - 1) / NT;
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
     for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + s] + 1);
     // (no barrier before re-staging XL: the previous chain's conv1s — XL's only readers — all ended on a barrier,
     //  and its last conv2 reads TB only)
-    stage();
+    stage(first ? gx0 : mrf_opaque(gx0));
     __syncthreads();
     for (int step = 0; step < a.nsteps; ++step) {
       const int dil = a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + step];
@@ -341,11 +349,29 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
         if (!(last && cv == 1) && !(MRF_ABL & 2)) __syncthreads();
       }
     }
-    // the MRF sum, in the reference's order (xs = rb0; xs += rb1; xs += rb2)
+    // the chain's result goes to this workgroup's output plane, in the reference's summation order (xs = rb0; xs += rb1):
+    // the first chain of a workgroup stores, the second adds to what the same lanes stored (a register-resident sum
+    // would hold 16 more VGPRs through the whole second chain — the difference between spilling and not at 3 per CU)
+    if (rows_ok) {
+      float* yb = (part == 0 ? a.y2 : a.y) + (long long)b * a.bs;
 #pragma unroll
-    for (int s = 0; s < CORE; ++s)
+      for (int s = 0; s < CORE; ++s) {
+        const int g = gx0 + col_of(s);
+        if (g < L) {
+          float* yp = yb + (long long)row0 * a.ld + g;
+          if (first) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sum[s][r] = first ? xres[s][r] : sum[s][r] + xres[s][r];
+            for (int r = 0; r < 4; ++r) yp[(long long)r * a.ld] = xres[s][r];
+          } else {
+            float prev[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prev[r] = yp[(long long)r * a.ld];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yp[(long long)r * a.ld] = prev[r] + xres[s][r];
+          }
+        }
+      }
+    }
   };
   if (part == 0) {
     prefetch(2, 0, 0);
@@ -354,18 +380,6 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
     prefetch(0, 0, 0);
     run_chain(K0, 0, true, 1);
     run_chain(K1, 1, false, -1);
-  }
-
-  if (rows_ok) {
-    float* yb = (part == 0 ? a.y2 : a.y) + (long long)b * a.bs;
-#pragma unroll
-    for (int s = 0; s < CORE; ++s) {
-      const int g = gx0 + col_of(s);
-      if (g < L) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yb[(long long)(row0 + r) * a.ld + g] = sum[s][r];
-      }
-    }
   }
 }
 

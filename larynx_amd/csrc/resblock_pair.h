@@ -112,6 +112,14 @@ struct PairGeom {
   static constexpr int XW = (T1 + (K - 1) * PAIR_DMAX + 4 + 3) & ~3;     // staged x row: tile + conv1 halo + alignment slack
   static constexpr int TW = (T1 + K + 3) & ~3;                           // parked conv1 row (+ slack for the masked tail reads)
   static constexpr int XS = C * XW, TS = C * TW;                         // LDS floats
+  // The parked conv1 tile lives in the SAME LDS as the x tile, behind the k-group reduction scratch: by the time it is
+  // written (after conv1's reduction) nothing reads x from LDS any more.  C = 64: 83 KB -> 52 KB, two workgroups per CU.
+#ifdef MI355TTS_PAIR_SPLIT_LDS  // A/B builds: the round-2 layout (x tile and parked tile side by side)
+  static constexpr int RED = XS;
+#else
+  static constexpr int RED = 4 * NB * 16 * 64;
+#endif
+  static constexpr int LDS = XS > RED + TS ? XS : RED + TS;
 };
 
 // One workgroup's tile: output columns [tile_x * T2, +T2) of batch row b.  xs / ts = PairGeom::XS / TS floats of LDS.
@@ -287,9 +295,9 @@ __device__ __forceinline__ void pair_tile(const PairArgs& a, const int tile_x, c
 }
 
 template <int K, int CB, int NB>
-__global__ __launch_bounds__(512) void resblock_pair_kernel(const PairArgs a) {
-  __shared__ float xs[PairGeom<K, CB, NB>::XS];
-  __shared__ float ts[PairGeom<K, CB, NB>::TS];
+__global__ __launch_bounds__(512, CB == 2 ? 4 : 1) void resblock_pair_kernel(const PairArgs a) {
+  __shared__ float xs[PairGeom<K, CB, NB>::LDS];
+  float* const ts = xs + PairGeom<K, CB, NB>::RED;
   int tile_x, tile_y;
   int gx = gridDim.x;
   if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (conv_mfma.h, row_tiles)
@@ -308,15 +316,11 @@ struct PairGroupArgs {
   int off[4];
 };
 template <int K0, int K1, int K2, int CB, int NB>
-__global__ __launch_bounds__(512) void pair_group_kernel(const PairGroupArgs g) {
-  constexpr int XS = PairGeom<K0, CB, NB>::XS > PairGeom<K1, CB, NB>::XS
-                         ? (PairGeom<K0, CB, NB>::XS > PairGeom<K2, CB, NB>::XS ? PairGeom<K0, CB, NB>::XS : PairGeom<K2, CB, NB>::XS)
-                         : (PairGeom<K1, CB, NB>::XS > PairGeom<K2, CB, NB>::XS ? PairGeom<K1, CB, NB>::XS : PairGeom<K2, CB, NB>::XS);
-  constexpr int TS = PairGeom<K0, CB, NB>::TS > PairGeom<K1, CB, NB>::TS
-                         ? (PairGeom<K0, CB, NB>::TS > PairGeom<K2, CB, NB>::TS ? PairGeom<K0, CB, NB>::TS : PairGeom<K2, CB, NB>::TS)
-                         : (PairGeom<K1, CB, NB>::TS > PairGeom<K2, CB, NB>::TS ? PairGeom<K1, CB, NB>::TS : PairGeom<K2, CB, NB>::TS);
-  __shared__ float xs[XS];
-  __shared__ float ts[TS];
+// (C = 64: capped at 128 VGPRs so that two of the 52 KB workgroups share a CU)
+__global__ __launch_bounds__(512, CB == 2 ? 4 : 1) void pair_group_kernel(const PairGroupArgs g) {
+  constexpr int L0 = PairGeom<K0, CB, NB>::LDS, L1 = PairGeom<K1, CB, NB>::LDS, L2 = PairGeom<K2, CB, NB>::LDS;
+  __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
+  float* const ts = xs + PairGeom<K0, CB, NB>::RED;
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
   // ragged batch: a row deals only its own tiles (conv_mfma.h, row_tiles)

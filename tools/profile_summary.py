@@ -8,9 +8,13 @@ import sys
 from pathlib import Path
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+# optional second argument "medium": the passes over tools/config4_probe.py (BASELINE config 4: thorsten + 'medium', batch 8)
+TAG = (sys.argv[2] + "_") if len(sys.argv) > 2 else ""
 SRC = Path("gpurun_out") / R
 DST = Path("profiles")
 DST.mkdir(exist_ok=True)
+ROUND = R
+R = R + ("_" + TAG[:-1] if TAG else "")
 
 
 def load(path):
@@ -20,9 +24,9 @@ def load(path):
     return d
 
 
-shutil.copy(SRC / "trace" / "trace_kernel_stats.csv", DST / f"{R}_kernel_stats.csv")
+shutil.copy(SRC / f"{TAG}trace" / "trace_kernel_stats.csv", DST / f"{R}_kernel_stats.csv")
 for name in ("fetch", "write", "sq"):
-    shutil.copy(SRC / f"pmc_{name}" / f"{name}_counter_collection_by_kernel.csv", DST / f"{R}_pmc_{name}_by_kernel.csv")
+    shutil.copy(SRC / f"{TAG}pmc_{name}" / f"{name}_counter_collection_by_kernel.csv", DST / f"{R}_pmc_{name}_by_kernel.csv")
 fetch, write, sq = (load(DST / f"{R}_pmc_{n}_by_kernel.csv") for n in ("fetch", "write", "sq"))
 stats = {r["Name"]: r for r in csv.DictReader(open(DST / f"{R}_kernel_stats.csv"))}
 
@@ -50,9 +54,14 @@ for full, st in stats.items():
                      fetch_kb=(f[1] / f[0]) if f else None, write_kb=(w[1] / w[0]) if w else None, mfma_util=util))
 rows.sort(key=lambda r: -r["pct"])
 with open(DST / f"{R}_summary.md", "w") as out:
-    out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config5 --no-half-mode --concurrency 1 --repeats 1`\n\n"
-              "(the product schedule of a call that has the GPU to itself: one stream, the three MRF chains' same-geometry convs / fused pairs as ONE "
-              "grouped launch — `conv_group_kernel` for the 256/128-channel stages, `pair_group_kernel` for the 64/32-channel stages)\n\n")
+    if TAG:
+        out.write(f"# {R}: rocprofv3 summary of `python tools/config4_probe.py 10` — BASELINE config 4: de-de thorsten GlowTTS + hifi_gan 'medium', "
+                  "ONE padded batch of 8 rows (P = 19 ... 120, 2200 frames) per fused call, single stream\n\n"
+                  "(`mrf_small_kernel` = a whole 16- / 8-channel stage per launch; `pair_group_kernel` = the 64- / 32-channel stages)\n\n")
+    else:
+        out.write(f"# {R}: rocprofv3 summary of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1`\n\n"
+                  "(the product schedule of a call that has the GPU to itself: one stream, the three MRF chains' same-geometry convs / fused pairs as ONE "
+                  "grouped launch — `conv_group_kernel` for the 256/128-channel stages, `pair_group_kernel` for the 64/32-channel stages)\n\n")
     out.write("Sources: `--kernel-trace --stats` (durations), separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and SQ passes "
               "(tools/profile_round.sh).  FETCH/WRITE are KB per dispatch as rocprofv3 reports them; on gfx950 FETCH_SIZE "
               "under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md §HBM) — the conv kernel reads its "
@@ -67,6 +76,8 @@ with open(DST / f"{R}_summary.md", "w") as out:
 # dominant kernel class = the HiFi-GAN ResBlock launches: LINEAR conv instances with K in {3,7,11}
 # (wide stages) plus the fused conv-pair kernel (32/64-channel stages)
 def is_dom(k):
+    if TAG:
+        return k.startswith("mrf_small_kernel")
     return k.startswith("pair_group_kernel") or k.startswith("conv_group_kernel") or k.startswith("resblock_pair_kernel")
 
 
@@ -77,7 +88,8 @@ traffic = sum(r["calls"] * ((r["fetch_kb"] or 0) + (r["write_kb"] or 0)) for r i
 # read both activations and weights) at exactly half its bytes — double it before comparing with a byte count
 traffic_corr = sum(r["calls"] * (2.0 * (r["fetch_kb"] or 0) + (r["write_kb"] or 0)) for r in dom) * 1024.0 / n
 avg_us = sum(r["calls"] * r["avg_us"] for r in dom) / n
-json.dump({"round": R, "kernel_class": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (64/32-channel stages)",
+json.dump({"round": R, "kernel_class": ("mrf_small_kernel (the 16- and 8-channel stages of 'medium', one launch per stage)" if TAG else
+                                        "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (64/32-channel stages)"),
            "dispatches": n, "avg_us": avg_us, "hbm_bytes_per_launch_raw": traffic, "hbm_bytes_per_launch": traffic_corr,
            "note": "FETCH_SIZE / WRITE_SIZE (KB x 1024) per dispatch from separate PMC passes; `hbm_bytes_per_launch` applies the "
                    "guide's gfx950 correction (FETCH_SIZE counts 16-B/lane streaming reads at half their bytes: x2 on the read "

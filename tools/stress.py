@@ -62,10 +62,16 @@ def unload_leg(eng, threads: int, seconds: float):
                 good = np.array_equal(i16, want[k])
                 with lock:
                     stats["ok" if good else "bad"] += 1
+                    if not good:
+                        stats.setdefault("errors", []).append(f"job {k}: int16 differs by {int(np.abs(i16.astype(np.int32) - want[k].astype(np.int32)).max())}")
             except ffi.Mi355ttsError as e:
                 with lock:
                     stats["no_model" if e.code == -5 else "bad"] += 1  # MI355TTS_ERR_NO_MODEL: looked the id up after the unload
+                    if e.code != -5:
+                        stats.setdefault("errors", []).append(str(e)[:120])
+                time.sleep(0.001)
 
+    eng.reserve(threads + 2, g0, v0, max_batch=1, max_ids=128, max_frames=128 * 12)  # workspaces sized up front: VRAM must come back flat
     used0 = vram_used()
     th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
     for t in th:
@@ -73,11 +79,11 @@ def unload_leg(eng, threads: int, seconds: float):
     t_end = time.perf_counter() + seconds
     cycles = 0
     while time.perf_counter() < t_end:
-        time.sleep(0.02)
+        time.sleep(0.05)
         old_g, old_v = ids["g"], ids["v"]
         eng.unload(old_g)  # in-flight calls keep their pin; new ones fail with NO_MODEL until the reload below
-        eng.set_option("mrf_group", cycles % 2)
-        eng.set_option("mrf_small", (cycles // 2) % 2)
+        eng.set_option("mrf_group", cycles % 2)  # (both schedules give the same bits; mrf_small changes the summation order)
+        eng.set_option("adaptive_schedule", (cycles // 2) % 2)
         time.sleep(0.005)
         ids["g"] = eng.load_glow(ghp, gsd)
         eng.unload(old_v)
@@ -87,7 +93,7 @@ def unload_leg(eng, threads: int, seconds: float):
     for t in th:
         t.join()
     eng.set_option("mrf_group", 1)
-    eng.set_option("mrf_small", 1)
+    eng.set_option("adaptive_schedule", 0)
     eng.unload(ids["g"])
     eng.unload(ids["v"])
     used1 = vram_used()
