@@ -189,6 +189,10 @@ def main():
         # -> ~620 frames), with recorded noise instead of the device RNG
         ("ljspeech_high_S120", HP.LJSPEECH, HP.HIFIGAN_HIGH,
          synthetic.synthetic_phoneme_ids(np.random.default_rng(1234), 120, HP.LJSPEECH.num_symbols), 0.667, 0.65),
+        # the upper end of BASELINE config 3's length range (P = 200 ids -> ~1000 frames = 11.7 s of audio) on 'high': a value
+        # check well past the standard utterance (multi-tile launches in every stage, the attention's 200 x 200 scores)
+        ("ljspeech_high_P200", HP.LJSPEECH, HP.HIFIGAN_HIGH,
+         synthetic.synthetic_phoneme_ids(np.random.default_rng(200), 200, HP.LJSPEECH.num_symbols), 0.667, 0.65),
     ]
     # BASELINE config 4: thorsten + 'medium', B = 8 variable length: the five thorsten fixture
     # sentences (19, 26, 31, 33, 64 ids) + synthetic rows of 47, 90, 120 ids.  The reference never batches
