@@ -290,8 +290,8 @@ def config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_
         "scaling": "weak",
         "roofline": {
             "narrow_stages": {
-                "kernel": "mrf_small_kernel: the 16- and 8-channel stages, all three ResBlock1 chains + their average per launch "
-                          "(v_mfma_f32_16x16x4_f32 on an LDS-resident tile)",
+                "kernel": "mrf_small_kernel (16 channels: v_mfma_f32_16x16x4_f32) + mrf8_kernel (8 channels: v_mfma_f32_4x4x1_16B_f32, no "
+                          "padding rows): a whole stage — all three ResBlock1 chains on LDS-resident tiles — per launch",
                 "bound": "mfma",
                 "why": "fused, a stage is 252 (C = 8) / 504 (C = 16) FLOP per byte of its one read + one write — far above the ~20 FLOP/B ridge",
                 "achieved": tf(narrow), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -583,8 +583,17 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   constexpr int T = 256;
   const dim3 grid(2 * ((Lmax + T - 1) / T), 1, B);  // two workgroups per tile
   ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
-  if (ms.C == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  static const bool mrf8_off = [] { const char* e = std::getenv("MI355TTS_NO_MRF8"); return e && std::atoi(e) != 0; }();
+  if (ms.C == 16) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  } else if (!mrf8_off) {
+    // 8 channels: the 4x4x1 16-block MFMA (no padding rows), its own fragment packing; two waves per tile
+    a.w = arena + ms.w8_off;
+    a.tab = reinterpret_cast<const int*>(arena + ms.t8_off);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf8_kernel<T, 3, 7, 11>), grid, dim3(128), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
+  }
   return 0;
 }
 

@@ -27,6 +27,7 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------ models
 struct DevConv {
   size_t w_off = 0, b_off = 0, t_off = 0;  // offsets (floats) into the model arena: fragments, biases, the int table
+  size_t w8_off = 0, t8_off = 0;           // C = 8: the 4x4x1 packing (mrf8_kernel) and its table
   const float* w = nullptr;
   const float* bias = nullptr;
   int mtiles = 0, noct = 0, K = 0, rows = 0, Cin = 0, Cout = 0, MB = 1;
@@ -166,6 +167,7 @@ struct MrfStage {
   bool ok = false;
   int C = 0, nsteps = 0;
   size_t w_off = 0, b_off = 0, t_off = 0;  // offsets (floats) into the model arena: fragments, biases, the int table
+  size_t w8_off = 0, t8_off = 0;           // C = 8: the 4x4x1 packing (mrf8_kernel) and its table
   int woff[3][MRF_MAX_STEPS][2] = {};
   int dil[3][MRF_MAX_STEPS] = {};
   double mac_per_col = 0;  // algorithmic MACs per output column (all 18 convs)

@@ -382,7 +382,8 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     // narrow stages additionally get the packing of the one-launch MRF kernel (mrf_small.h): ResBlock1 chains
     // with taps (3, 7, 11), <= 3 dilation steps and a receptive half-width within the staged halo
     MrfStage ms;
-    std::vector<float> mrf_w, mrf_b;
+    std::vector<float> mrf_w, mrf_b, mrf_w8;
+    int woff8[3][MRF_MAX_STEPS][2] = {};
     ms.ok = h.resblock_type == 1 && h.num_kernels == 3 && (ch == 8 || ch == 16) && h.num_dilations <= MRF_MAX_STEPS &&
             h.resblock_kernel_sizes[0] == 3 && h.resblock_kernel_sizes[1] == 7 && h.resblock_kernel_sizes[2] == 11;
     for (int j = 0; ms.ok && j < h.num_kernels; ++j) {
@@ -421,6 +422,11 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
               std::vector<float> pk = pack_mrf_conv(ch, k, [&](int co, int ci, int kk) { return wsrc[((size_t)co * ch + ci) * k + kk]; });
               ms.woff[j][d][cv] = (int)mrf_w.size();
               mrf_w.insert(mrf_w.end(), pk.begin(), pk.end());
+              if (ch == 8) {
+                std::vector<float> p8 = pack_mrf8_conv(k, [&](int co, int ci, int kk) { return wsrc[((size_t)co * ch + ci) * k + kk]; });
+                woff8[j][d][cv] = (int)mrf_w8.size();
+                mrf_w8.insert(mrf_w8.end(), p8.begin(), p8.end());
+              }
               std::memcpy(&mrf_b[(((size_t)j * MRF_MAX_STEPS + d) * 2 + cv) * 16], bs[cv], sizeof(float) * ch);
             }
             ms.mac_per_col += 2.0 * ch * ch * k;
@@ -446,6 +452,16 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
         }
       static_assert(sizeof(int) == sizeof(float), "the table rides in the float arena");
       ms.t_off = ab.add(reinterpret_cast<const float*>(tab), MRF_TAB_INTS);
+      if (ch == 8) {
+        mrf_w8.resize(mrf_w8.size() + 64, 0.f);  // the tap loop's prefetch reads one fragment past the last conv
+        ms.w8_off = ab.add(mrf_w8);
+        for (int j = 0; j < 3; ++j)
+          for (int d = 0; d < MRF_MAX_STEPS; ++d) {
+            tab[(j * MRF_MAX_STEPS + d) * 2 + 0] = woff8[j][d][0];
+            tab[(j * MRF_MAX_STEPS + d) * 2 + 1] = woff8[j][d][1];
+          }
+        ms.t8_off = ab.add(reinterpret_cast<const float*>(tab), MRF_TAB_INTS);
+      }
     }
     hm->mrf.push_back(ms);
   }

@@ -383,4 +383,243 @@ __global__ __launch_bounds__(64 * NW, MRF_OCC(T, NW)) void mrf_small_kernel(cons
   }
 }
 
+
+// =====================================================================================================================
+// The 8-channel stage on v_mfma_f32_4x4x1_16B_f32 (round 3): with C = 8 the 16-row MFMA above runs half its rows on
+// padding.  The 16-block 4 x 4 x 1 form with CBSZ = 4 broadcasts ONE block's A to all sixteen: D[i][lane] += A[4*ABID + i] *
+// B[lane], i = 0..3 — a 4-row x 64-column rank-1 update, two of which (ABID = 2 ci, 2 ci + 1) cover the 8 output channels of
+// 64 columns for one (input channel, tap) at the full f32 matrix rate with no padding at all:
+//   A: ONE register per tap holds W[co][ci][tap] for all 8 x 8 (co, ci) pairs — lane = 8 ci + co — and ABID picks the input
+//      channel: one coalesced 256-byte load per tap feeds 16 MFMAs per 64-column block;
+//   B: lane l holds x[ci][c0 + l + tap * dil]: 64 consecutive floats of one LDS row, one conflict-free ds_read_b32;
+//   D: two float4 per 64-column block: a lane owns all 8 channels of ONE column.
+// Blocks are 64 columns on the tile's own grid: [left halo | T / 64 core blocks | right halo].  Two waves per workgroup: wave 0
+// owns the left halo block and the first half of the core, wave 1 the second half and the right halo block — every conv but
+// a chain's last runs T / 128 + 1 blocks on each wave (balanced; the last one the core only), a lane keeps its columns from
+// conv to conv, so the raw residual stream stays in registers and LDS holds two planes (26 KB: six workgroups per CU).
+template <int T, int NB>
+__device__ __forceinline__ void mrf8_conv_taps(floatx4 (&acc)[T / 128 + 1][2], float& an, const float* __restrict__ wp,
+                                               const float* __restrict__ pcore, const float* __restrict__ phalo, const int dil, const int K) {
+  constexpr int W = T + 2 * MRF_HALO + 16;
+  constexpr int CPW = T / 128;  // core blocks per wave; slot CPW (when NB > CPW) is the wave's halo block
+  // one step = one input channel of one tap = 2 * NB MFMAs (8 cycles each); the next step's B reads are pinned behind them,
+  // operands alternate between two register sets (no moves)
+  auto bread = [&](int s, int ci) -> float { return s < CPW ? pcore[ci * W + 64 * s] : phalo[ci * W]; };
+  float b0[NB], b1[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) b0[s] = bread(s, 0);
+  const float* wt = wp + 64;  // the next tap's fragment
+#pragma unroll 1
+  for (int tap = 0; tap < K; ++tap) {
+    const float av = an;
+    an = wt[0];  // (reads one tap past the conv on the last iteration: the next conv's fragment or the arena's slack)
+    wt += 64;
+    // (ABID must be a literal: the eight input channels are spelled out)
+#define MRF8_STEP(ci, BC, BN)                                                                      \
+  {                                                                                                \
+    if (ci + 1 < 8) {                                                                              \
+      _Pragma("unroll") for (int s = 0; s < NB; ++s) BN[s] = bread(s, ci + 1);                     \
+    } else {                                                                                       \
+      pcore += dil;                                                                                \
+      phalo += dil;                                                                                \
+      _Pragma("unroll") for (int s = 0; s < NB; ++s) BN[s] = bread(s, 0);                          \
+    }                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < NB; ++s) {                                               \
+      acc[s][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, BC[s], acc[s][0], 4, 2 * ci, 0);          \
+      acc[s][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, BC[s], acc[s][1], 4, 2 * ci + 1, 0);      \
+    }                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < NB; ++s) {                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+      if (s == 0 && ci == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+    MRF8_STEP(0, b0, b1) MRF8_STEP(1, b1, b0) MRF8_STEP(2, b0, b1) MRF8_STEP(3, b1, b0)
+    MRF8_STEP(4, b0, b1) MRF8_STEP(5, b1, b0) MRF8_STEP(6, b0, b1) MRF8_STEP(7, b1, b0)
+#undef MRF8_STEP
+  }
+}
+
+// grid = (2 * tiles, 1, B): workgroup kinds as in mrf_small_kernel (part 0: the K2 chain -> y2; part 1: K0 then K1 -> y).
+// a.w / a.tab hold the 4x4x1 packing (pack_mrf8_conv): per conv [tap][64 lanes], lane = 8 * ci + co.
+template <int T, int K0, int K1, int K2>
+__global__ __launch_bounds__(128) void mrf8_kernel(const MrfArgs a) {
+  constexpr int C = 8, W = T + 2 * MRF_HALO + 16, NCOL = T + 2 * MRF_HALO;
+  constexpr int CPW = T / 128, NS = CPW + 1;  // slots per wave: its core blocks, then its halo block
+  constexpr int NT = 128;
+  static_assert(T % 128 == 0, "two waves split the core blocks evenly");
+  __shared__ float lds[64 + 2 * C * W + 128];
+  float* const XL = lds + 64;     // lrelu(current x): conv1's operand
+  float* const TB = XL + C * W;   // lrelu(conv1 + bias): conv2's operand
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int b = blockIdx.z;
+  int tile_x, tile_y;
+  const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
+  const int gx = gridDim.z > 1 ? row_tiles(L, T) : (int)gridDim.x / 2;
+  const int lin = blockIdx.x;
+  if (lin >= 2 * gx) return;
+  const int chunk = lin / (2 * MRF_MIX), rr = lin - chunk * (2 * MRF_MIX);
+  const int n_in = gx - chunk * MRF_MIX < MRF_MIX ? gx - chunk * MRF_MIX : MRF_MIX;
+  const int part = rr / n_in;
+  xcd_tile_lin(chunk * MRF_MIX + (rr - part * n_in), gx, 1, tile_x, tile_y);
+  const int j0 = tile_x * T;
+  if (j0 >= L) return;
+  const int gx0 = j0 - MRF_HALO;
+  const float slope = a.slope;
+  const float* xb = a.x + (long long)b * a.bs;
+
+  // this lane's LDS column in each slot: core blocks 1 + wave * CPW + s, the halo block 0 (wave 0) / 1 + T / 64 (wave 1)
+  const int core_col = 64 * (1 + wave * CPW) + lane;
+  const int halo_col = (wave == 0 ? 0 : 64 * (1 + T / 64)) + lane;
+  auto col_of = [&](int s) -> int { return s < CPW ? core_col + 64 * s : halo_col; };
+  auto inside = [&](int s) -> bool {
+    const int g = gx0 + col_of(s);
+    return g >= 0 && g < L;
+  };
+
+  floatx4 acc[NS][2];
+  float xres[NS][8];  // the raw residual stream of the columns this lane owns
+  float an;           // tap 0's fragment of the NEXT conv
+  float bn[8];        // its bias
+
+  auto stage = [&](const int gx0) __attribute__((always_inline)) {
+    constexpr int F4 = NCOL / 4;
+    constexpr int NF4 = C * F4;
+    constexpr int NE = (NF4 + NT - 1) / NT;
+    const int ld_last4 = a.ld - 4;
+    float4 pre[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      pre[i] = *reinterpret_cast<const float4*>(xb + (row < C ? row : C - 1) * a.ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + NT * i;
+      const int row = e / F4, f = e - row * F4;
+      const int c0 = gx0 + 4 * f;
+      float4 v = pre[i];
+      v.x = (c0 >= 0 && c0 < L) ? v.x : 0.f;
+      v.y = (c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+      v.z = (c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+      v.w = (c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+      v.x = v.x > 0.f ? v.x : v.x * slope;
+      v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope;
+      v.w = v.w > 0.f ? v.w : v.w * slope;
+      if (e < NF4) *reinterpret_cast<float4*>(XL + row * W + 4 * f) = v;
+    }
+    // the raw residual stream of the owned columns, straight from global memory (L2-hot): 256-byte rows per block
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bool in = inside(s);
+      const float* xp = xb + (in ? gx0 + col_of(s) : 0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xres[s][r] = xp[(long long)r * a.ld];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xres[s][r] = in ? xres[s][r] : 0.f;
+    }
+  };
+  auto prefetch = [&](int chain, int step, int cv) __attribute__((always_inline)) {
+    an = a.w[a.tab[(chain * MRF_MAX_STEPS + step) * 2 + cv] + lane];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bn[r] = a.bias[((chain * MRF_MAX_STEPS + step) * 2 + cv) * 16 + r];
+  };
+
+  auto run_chain = [&](const int K, const int chain, const bool first, const int next_chain) __attribute__((always_inline)) {
+    const int P2 = (K - 1) / 2;
+    int need = 0;
+    for (int s = 0; s < a.nsteps; ++s) need += P2 * (a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + s] + 1);
+    // (no barrier before re-staging XL: the previous chain's conv1s — XL's only readers — all ended on a barrier)
+    stage(first ? gx0 : mrf_opaque(gx0));
+    __syncthreads();
+    for (int step = 0; step < a.nsteps; ++step) {
+      const int dil = a.tab[MRF_TAB_DIL + chain * MRF_MAX_STEPS + step];
+      const bool last = step == a.nsteps - 1;
+#pragma unroll
+      for (int cv = 0; cv < 2; ++cv) {
+        const int d = cv == 0 ? dil : 1;
+        need -= P2 * d;  // what the LATER convs still need beyond the core on either side: > 0 -> the halo blocks run too
+        const float* wp = a.w + a.tab[(chain * MRF_MAX_STEPS + step) * 2 + cv] + lane;
+        const float* src = cv == 0 ? XL : TB;
+        float bb[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bb[r] = bn[r];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[s][0] = floatx4{bb[0], bb[1], bb[2], bb[3]};
+          acc[s][1] = floatx4{bb[4], bb[5], bb[6], bb[7]};
+        }
+        const int nb = need > 0 ? NS : CPW;
+        if (need > 0) mrf8_conv_taps<T, NS>(acc, an, wp, src + core_col - P2 * d, src + halo_col - P2 * d, d, K);
+        else mrf8_conv_taps<T, CPW>(acc, an, wp, src + core_col - P2 * d, src + halo_col - P2 * d, d, K);
+        if (cv == 0) prefetch(chain, step, 1);
+        else if (!last) prefetch(chain, step + 1, 0);
+        else if (next_chain >= 0) prefetch(next_chain, 0, 0);
+        const bool final_conv = last && cv == 1;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (s < nb) {
+            const bool in = inside(s);
+            if (cv == 0) {
+              float* tp = TB + col_of(s);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                float v = acc[s][r >> 2][r & 3];
+                v = v > 0.f ? v : v * slope;
+                tp[r * W] = in ? v : 0.f;
+              }
+            } else {
+              float* xp = XL + col_of(s);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const float v = in ? acc[s][r >> 2][r & 3] + xres[s][r] : 0.f;
+                xres[s][r] = v;
+                if (!last) xp[r * W] = v > 0.f ? v : v * slope;
+              }
+            }
+          }
+        }
+        if (!final_conv) __syncthreads();
+      }
+    }
+    // the chain's result (core columns) goes to this workgroup's plane: the first chain stores, the second adds
+    {
+      float* yb = (part == 0 ? a.y2 : a.y) + (long long)b * a.bs;
+#pragma unroll
+      for (int s = 0; s < CPW; ++s) {
+        const int g = gx0 + col_of(s);
+        if (g < L) {
+          float* yp = yb + g;
+          if (first) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) yp[(long long)r * a.ld] = xres[s][r];
+          } else {
+            float prev[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) prev[r] = yp[(long long)r * a.ld];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) yp[(long long)r * a.ld] = prev[r] + xres[s][r];
+          }
+        }
+      }
+    }
+  };
+  if (part == 0) {
+    prefetch(2, 0, 0);
+    run_chain(K2, 2, true, -1);
+  } else {
+    prefetch(0, 0, 0);
+    run_chain(K0, 0, true, 1);
+    run_chain(K1, 1, false, -1);
+  }
+}
+
 }  // namespace mi355tts

@@ -122,4 +122,15 @@ inline std::vector<float> pack_mrf_conv(int C, int K, WGet wget) {
   return p;
 }
 
+// A fragments for mrf8_kernel (v_mfma_f32_4x4x1_16B_f32 with CBSZ = 4): one conv w[8][8][K] as [tap][64 lanes], lane = 8 ci + co —
+// ABID = 2 ci (+ 1) then broadcasts W[0..3 (4..7)][ci][tap] to all sixteen 4-column blocks.
+template <typename WGet>
+inline std::vector<float> pack_mrf8_conv(int K, WGet wget) {
+  std::vector<float> p((size_t)K * 64, 0.f);
+  for (int k = 0; k < K; ++k)
+    for (int ci = 0; ci < 8; ++ci)
+      for (int co = 0; co < 8; ++co) p[(size_t)k * 64 + 8 * ci + co] = wget(co, ci, k);
+  return p;
+}
+
 }  // namespace mi355tts

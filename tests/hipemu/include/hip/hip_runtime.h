@@ -191,6 +191,25 @@ inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   return c;
 }
 
+// v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 x 4 x 1 — block b takes A[i] from lane 4b + i and B[j] from lane 4b + j and
+// holds D_b[i][j] in register i of lane 4b + j.  CBSZ = n broadcasts A inside sets of 2^n blocks: every block of a set reads
+// block (set base + ABID)'s A.  (CBSZ = 4, ABID = k: all 16 blocks use the A of lanes 4k .. 4k + 3 — a 4-row x 64-column
+// rank-1 update, how composable_kernel drives it.)
+inline f32x4 mfma_f32_4x4x1(float a, float b, f32x4 c, int cbsz, int abid) {
+  BlockCtx* cx = ctx();
+  Fiber* f = cx->cur;
+  WaveState& w = cx->waves[f->wave];
+  const int l = f->lane;
+  w.A[l] = a;
+  wave_barrier();
+  const int blk = l >> 2;
+  const int set = cbsz > 0 ? (blk >> cbsz) << cbsz : blk;
+  const int src = cbsz > 0 ? set + (abid & ((1 << cbsz) - 1)) : blk;
+  for (int i = 0; i < 4; ++i) c[i] = std::fmaf(w.A[4 * src + i], b, c[i]);
+  wave_barrier();
+  return c;
+}
+
 // v_mfma_f32_32x32x16_bf16: lane l supplies 8 consecutive k of A row l&31 and of B column l&31,
 // k = 8*(l>>5) .. +7; D as for the 32x32 f32 MFMA.  Products of bf16 values are exact in f32;
 // accumulated here in k order (the hardware's internal order is not specified — tests allow for it).
@@ -246,6 +265,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_f32_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_f32_16x16x4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, cbsz, abid, blgp) hipemu::mfma_f32_4x4x1((a), (b), (c), (cbsz), (abid))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -99,6 +99,10 @@ def test_narrow_stage_kernel_fits_three_workgroups_per_cu(resources):
     assert len(mrf) == 2
     for n, r in mrf.items():
         assert r["vgprs"] <= 168 and r["scratch"] == 0 and r["lds"] <= 53 * 1024 and r["occupancy"] >= 3, (n, r)
+    mrf8 = {n: r for n, r in resources.items() if "mrf8_kernel" in n}  # the 8-channel stage on the 4x4x1 MFMA: 2 waves, 26 KB
+    assert len(mrf8) == 1
+    for n, r in mrf8.items():
+        assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["lds"] <= 27 * 1024, (n, r)
 
 
 def test_two_workgroups_per_cu_where_the_schedule_counts_on_it(resources):

@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
     for (int d = 0; d < 3; ++d) {
       for (int cv = 0; cv < 2; ++cv) {
         tab[(j * 3 + d) * 2 + cv] = (int)w.size();
+#ifdef MRF_K8  // the 4x4x1 packing of mrf8_kernel: [tap][64]
+        for (int i = 0; i < Ks[j] * 64; ++i) w.push_back((rand() / (float)RAND_MAX - 0.5f) * 0.1f);
+#else
         for (int i = 0; i < Ks[j] * (C / 4) * 64; ++i) w.push_back(((i & 15) < C) ? (rand() / (float)RAND_MAX - 0.5f) * 0.1f : 0.f);
+#endif
       }
       tab[MRF_TAB_DIL + j * 3 + d] = dil[d];
     }
@@ -53,11 +57,16 @@ int main(int argc, char** argv) {
   a.w = dw; a.bias = db; a.tab = dt; a.nsteps = 3; a.slope = 0.1f;
   dim3 grid(2 * ((Lmax + MRF_T - 1) / MRF_T), 1, B);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<MRF_C, MRF_T, MRF_NW, 3, 7, 11>), grid, dim3(64 * MRF_NW), 0, 0, a);
+#ifdef MRF_K8
+#define MRF_LAUNCH hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf8_kernel<MRF_T, 3, 7, 11>), grid, dim3(128), 0, 0, a)
+#else
+#define MRF_LAUNCH hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<MRF_C, MRF_T, MRF_NW, 3, 7, 11>), grid, dim3(64 * MRF_NW), 0, 0, a)
+#endif
+  for (int i = 0; i < 3; ++i) MRF_LAUNCH;
   CK(hipDeviceSynchronize());
   const int N = 20;
   CK(hipEventRecord(e0));
-  for (int i = 0; i < N; ++i) hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<MRF_C, MRF_T, MRF_NW, 3, 7, 11>), grid, dim3(64 * MRF_NW), 0, 0, a);
+  for (int i = 0; i < N; ++i) MRF_LAUNCH;
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = 1e3 * ms / N, flop = 2.0 * 2.0 * C * C * 21 * 3 * (double)Lsum;
