@@ -54,9 +54,12 @@ constexpr int conv_bf16_lds_units() {
 // KS = 2 splits the K-dim between two groups of waves — group kg takes slab kg of every 32-channel chunk — and sums
 // the two partial tiles through LDS: launches with too few tiles to fill the chip (stage 0 of 'high' at batch 1:
 // 256 channels x 4992 columns = 78 tiles of 128 x 128 per conv) then put 8 waves on every tile instead of 4.
-template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1>
+// EPI = EPI_LINEAR (ResBlock convs) or EPI_UPSAMPLE (the polyphase ConvTranspose1d of conv_mfma.h: virtual rows co * u + r
+// scattered to y[co][q * u + r - up_pad]; its input may be the MRF average (x + x2 + x3) / in_div of the previous stage).
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1, int EPI = EPI_LINEAR>
 __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, uint4* __restrict__ xs) {
   static_assert(KS == 1 || KS == 2, "k-split of the bf16 tile is 1 or 2");
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "bf16 tile epilogues");
   constexpr int NWAVES = WM * WN * KS;
   constexpr int NT = 64 * NWAVES;
   constexpr int T_T = 32 * NB * WN;   // time columns per workgroup
@@ -80,10 +83,13 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
 
   const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
   const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
-  if (t0 >= Lout) return;  // uniform per workgroup
+  const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;  // extent of the GEMM's N axis
+  if (t0 >= n_len) return;  // uniform per workgroup
 
   const float slope = a.in_slope;
   const float* xb = a.x + (long long)b * a.x_bs;
+  const float* xb2 = a.x2 ? a.x2 + (long long)b * a.x_bs : nullptr;
+  const float* xb3 = a.x3 ? a.x3 + (long long)b * a.x_bs : nullptr;
   const int nchunks = (a.Cin + 31) / 32;
   const int PA = (a.pad + 3) & ~3;
   const int cin_last = a.Cin - 1;
@@ -103,6 +109,21 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
       for (int j = 0; j < 8; ++j) {
         const int ci = chunk * 32 + 8 * o + j;
         pre[i][j] = *reinterpret_cast<const float4*>(xb + (long long)(ci < a.Cin ? ci : cin_last) * a.x_ld + cc);
+      }
+      if (xb2) {  // wave-uniform: the MRF average of the previous stage's chain outputs, taken on load (this path waits)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = chunk * 32 + 8 * o + j;
+          const long long off = (long long)(ci < a.Cin ? ci : cin_last) * a.x_ld + cc;
+          float4 t2 = *reinterpret_cast<const float4*>(xb2 + off);
+          float4& p = pre[i][j];
+          p.x += t2.x; p.y += t2.y; p.z += t2.z; p.w += t2.w;
+          if (xb3) {
+            t2 = *reinterpret_cast<const float4*>(xb3 + off);
+            p.x += t2.x; p.y += t2.y; p.z += t2.z; p.w += t2.w;
+          }
+          p.x = p.x / a.in_div; p.y = p.y / a.in_div; p.z = p.z / a.in_div; p.w = p.w / a.in_div;
+        }
       }
     }
   };
@@ -309,9 +330,56 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
     if (kg != 0) return;
   }
 
-  // ---- epilogue: bias, residual, scale, accumulate; loads batched from clamped addresses
   const int col = lane & 31;
   const int rbase = 4 * (lane >> 5);
+  if constexpr (EPI == EPI_UPSAMPLE) {
+    // polyphase scatter (conv_mfma.h): registers 4g .. 4g+3 of a lane are 4 consecutive virtual rows = 4 consecutive phases
+    // of ONE output channel = 4 consecutive output samples: one float4 store where the alignment allows
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float bb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        bb[r] = (a.bias && row < a.rows) ? a.bias[row] : 0.f;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int q = t0 + (wn * NB + nb) * 32 + col;
+        if (q >= n_len) continue;
+        const bool vec = (a.up & 3) == 0 && (a.up_pad & 3) == 0 && (a.y_ld & 3) == 0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int row0 = (mt0 + mb) * 32 + 8 * g4 + rbase;
+          if (row0 >= a.rows) continue;
+          if (vec) {
+            const int co = row0 / a.up;
+            const int n0 = q * a.up + (row0 - co * a.up) - a.up_pad;
+            float* dst = a.y + (long long)b * a.y_bs + (long long)co * a.y_ld + n0;
+            if (n0 >= 0 && n0 + 3 < Lout) {
+              *reinterpret_cast<float4*>(dst) = make_float4(acc[mb][nb][4 * g4] + bb[4 * g4], acc[mb][nb][4 * g4 + 1] + bb[4 * g4 + 1],
+                                                            acc[mb][nb][4 * g4 + 2] + bb[4 * g4 + 2], acc[mb][nb][4 * g4 + 3] + bb[4 * g4 + 3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n0 + e >= 0 && n0 + e < Lout) dst[e] = acc[mb][nb][4 * g4 + e] + bb[4 * g4 + e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = row0 + e;
+              if (row >= a.rows) continue;
+              const int co = row / a.up;
+              const int n = q * a.up + (row - co * a.up) - a.up_pad;
+              if (n >= 0 && n < Lout) a.y[(long long)b * a.y_bs + (long long)co * a.y_ld + n] = acc[mb][nb][4 * g4 + e] + bb[4 * g4 + e];
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- epilogue: bias, residual, scale, accumulate; loads batched from clamped addresses
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     float bb[16];
@@ -357,18 +425,18 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
   }
 }
 
-template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1>
+template <int K, int MB, int NB, int WM, int WN, int HALO, int TERMS, int KS = 1, int EPI = EPI_LINEAR>
 __global__ __launch_bounds__(64 * WM * WN * KS) void conv_bf16_kernel(const ConvArgs a) {
   __shared__ uint4 xs[conv_bf16_lds_units<NB, WN, HALO>()];
   int tile_x, tile_y;
   int gx = gridDim.x;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
   if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (conv_mfma.h, row_tiles)
-    gx = row_tiles(conv_n_len<K, EPI_LINEAR>(a, blockIdx.z), 32 * NB * WN);
+    gx = row_tiles(conv_n_len<K, EPI>(a, blockIdx.z), 32 * NB * WN);
     if (lin >= gx * (int)gridDim.y) return;
   }
   xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
-  conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS, KS>(a, tile_x, tile_y, blockIdx.z, xs);
+  conv_bf16_tile<K, MB, NB, WM, WN, HALO, TERMS, KS, EPI>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // The three MRF chains' same-geometry convs in ONE launch (see conv_group_kernel).

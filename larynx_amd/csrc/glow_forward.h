@@ -126,6 +126,9 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   const int k = h.kernel_size, nh = h.n_heads;
   const bool in_dev = (flags & MI355TTS_IN_DEVICE) != 0;
   const int enc_host_len = B == 1 ? id_lens[0] : -1;
+  // workgroup target per GlowTTS conv launch (tile-shape choice; tuning knob MI355TTS_GLOW_TILES)
+  static const int glow_tiles_env = [] { const char* e = std::getenv("MI355TTS_GLOW_TILES"); return e ? std::atoi(e) : 0; }();
+  const int glow_tiles = glow_tiles_env > 0 ? glow_tiles_env : 1024;
   {
     long long sum = 0;
     for (int b = 0; b < B; ++b) sum += id_lens[b];
@@ -171,20 +174,20 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const float* cur = x;
     for (int i = 0; i < h.prenet_layers; ++i) {
       ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
-      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
       cur = t2;
     }
     ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
     a.res = x;
-    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
   }
   for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
     const GlowLayer& L = gm->layers[l];
     {
       ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
-      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -205,43 +208,43 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     {
       ConvArgs a = base_args(t2, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, 0);
       a.res = x;
-      CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g1, A + L.b1, x, H, bsH, P, d_len, B, Pmax, 0);
     }
     {  // FFN, attentions.py:375-383
       ConvArgs a = base_args(x, bsH, P, d_len, 1, ffn, (long long)Fc * P, P, d_len, 1, 1, k / 2);
       a.out_act = ACT_RELU;
-      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
       ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
       c.res = x;
-      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
     }
   }
   {  // proj_m and the duration predictor (models.py:133-139, 39-49)
     ConvArgs a = base_args(x, bsH, P, d_len, 1, xm, (long long)M * P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     float* d1 = ffn;
     float* d2 = ffn + (size_t)B * Fd * P;
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, 1024, enc_host_len));
+    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
   }
 
   // ---- durations -> frame counts (the one host sync of the path)
@@ -357,14 +360,14 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const GlowBlock& Bk = gm->blocks[blk];
     {  // CouplingBlock reverse (attentions.py:119-142): h = start(x0)
       ConvArgs a = base_args(z, bsZ, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
-      CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
     }
     int dil = 1;
     for (int j = 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
       a.half = H;
-      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       if (j < h.n_block_layers - 1) {
         r.res = hbuf;  // x = x + res_skip[:H]
@@ -376,7 +379,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       r.y2_bs = bsD;
       r.y2_ld = F2;
       r.accum2 = j > 0;
-      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       dil *= h.dilation_rate;
     }
     {  // m, logs = end(wn_out);  z1 = (x1 - m) * exp(-logs)
@@ -390,7 +393,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
         a.mix_bias = A + Bk.an_bias;
         a.mix_scale = A + Bk.an_scale;
       }
-      CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV, nullptr, 1024, dec_host_len));
+      CHECK(launch_conv(ctx, w, Bk.end, a, EPI_COUPLING, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       if (fuse_mix) continue;
     }
     {

@@ -257,7 +257,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
       a.in_slope = 0.1f;
       a.up = u;
       a.up_pad = (ku - u) / 2;
-      CHECK(launch_conv(ctx, w, hm->ups[i], a, EPI_UPSAMPLE, B, Lin + ku / u - 1, KC_UPSAMPLE, nullptr, 1024, voc_host_len));
+      CHECK(launch_conv(ctx, w, hm->ups[i], a, EPI_UPSAMPLE, B, Lin + ku / u - 1, KC_UPSAMPLE, nullptr, 1024, voc_host_len, prec));
     }
     mul *= u;
     ch = cout;

@@ -154,12 +154,23 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   a.noct = c.noct;
   a.Cin = c.Cin;
   a.rows = c.rows;
-  if ((precision == MI355TTS_PRECISION_BF16X3 || precision == MI355TTS_PRECISION_BF16) && c.w16 && epi == EPI_LINEAR && !a.x2 && !a.y2 && a.split >= c.rows && a.out_act == ACT_NONE &&
-      (c.K == 3 || c.K == 5 || c.K == 7 || c.K == 11) && (a.x_ld % 4) == 0 &&
-      (c.K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= (c.K == 3 ? 16 : c.K == 5 ? 28 : c.K == 7 ? 76 : 56)) {
+  const bool half_on = (precision == MI355TTS_PRECISION_BF16X3 || precision == MI355TTS_PRECISION_BF16) && c.w16 && (a.x_ld % 4) == 0;
+  const bool bf_linear = half_on && epi == EPI_LINEAR && !a.x2 && !a.y2 && a.split >= c.rows && a.out_act == ACT_NONE &&
+                         (c.K == 3 || c.K == 5 || c.K == 7 || c.K == 11) &&
+                         (c.K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= (c.K == 3 ? 16 : c.K == 5 ? 28 : c.K == 7 ? 76 : 56);
+  // the polyphase upsamplers (two taps) in the split-bf16 mode too: 0.24 ms of f32 work per 'high' utterance otherwise
+  static const bool no_bf_ups = [] { const char* e = std::getenv("MI355TTS_NO_BF16_UPS"); return e && std::atoi(e) != 0; }();
+  const bool bf_ups = half_on && !no_bf_ups && epi == EPI_UPSAMPLE && c.K == 2 && (c.K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= 4;
+  if (bf_linear || bf_ups) {
     a.w16 = c.w16;
     a.nslab = c.nslab16;
     a.rows_major = 0;
+    if (epi == EPI_UPSAMPLE) {
+      // deal ROW tiles to the XCDs when the weights are the bigger operand and the input fits an L2 (stage 0: 8.4 MB of
+      // fragments against 1.3 MB of input) — as the f32 path does
+      const double w_bytes = (double)c.mtiles16 * c.nslab16 * c.K * 2048.0, x_bytes = (double)c.Cin * (double)n_max * 4.0 * B;
+      a.rows_major = (w_bytes > x_bytes && x_bytes < 3.0e6 && c.mtiles16 >= 32) ? 1 : 0;
+    }
     int cfg, rows_t, cols_t;
     if (c.mtiles16 % 4 == 0) {
       const long long tiles_a = (long long)((n_max + 127) / 128) * (c.mtiles16 / 4) * B;
@@ -184,7 +195,7 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     out->cls = cls;
     out->bf16 = precision == MI355TTS_PRECISION_BF16 ? 1 : 3;
     out->grid = dim3((n_max + cols_t - 1) / cols_t, (c.mtiles16 * 32) / rows_t, B);
-    out->flop = 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B;
+    out->flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
     out->empty = false;
     return 0;
   }
@@ -279,6 +290,22 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   } else {                         \
     BF16_LAUNCH_T(KK, 1);          \
   }
+#define BF16_UPS_T(TT)                                                                                                                              \
+  if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<2, 1, 4, 4, 1, 4, TT, 1, EPI_UPSAMPLE>), grid, dim3(256), 0, s, a);      \
+  else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<2, 1, 1, 4, 1, 4, TT, 1, EPI_UPSAMPLE>), grid, dim3(256), 0, s, a); \
+  else if (shape == BF_C) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<2, 1, 2, 2, 2, 4, TT, 1, EPI_UPSAMPLE>), grid, dim3(256), 0, s, a); \
+  else if (shape == BF_K) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<2, 1, 4, 4, 1, 4, TT, 2, EPI_UPSAMPLE>), grid, dim3(512), 0, s, a); \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<2, 1, 1, 1, 4, 4, TT, 1, EPI_UPSAMPLE>), grid, dim3(256), 0, s, a)
+    if (p.epi == EPI_UPSAMPLE) {
+      if (p.K != 2) return fail(MI355TTS_ERR_INVALID, "bf16 upsampler needs two taps");
+      if (p.bf16 == 3) {
+        BF16_UPS_T(3);
+      } else {
+        BF16_UPS_T(1);
+      }
+      return 0;
+    }
+#undef BF16_UPS_T
     switch (p.K) {
       case 3: BF16_LAUNCH(3); break;
       case 5: BF16_LAUNCH(5); break;
@@ -320,9 +347,9 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
 }
 
 static int launch_conv(mi355tts_ctx* ctx, Worker* w, const DevConv& c, ConvArgs a, int epi, int B, int n_max, int cls,
-                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1) {
+                       hipStream_t stream = nullptr, int min_tiles = 1024, int host_len = -1, int precision = 0) {
   ConvPlan p;
-  CHECK(plan_conv(c, a, epi, B, n_max, cls, min_tiles, host_len, &p));
+  CHECK(plan_conv(c, a, epi, B, n_max, cls, min_tiles, host_len, &p, precision));
   return run_plan(ctx, w, p, stream);
 }
 

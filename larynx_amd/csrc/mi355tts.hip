@@ -377,6 +377,20 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     TAKE(w, "ups." + std::to_string(i) + ".weight", (int64_t)cin * cout * ku);
     TAKE(b, "ups." + std::to_string(i) + ".bias", cout);
     hm->ups.push_back(add_conv(ab, w, b, cout, cin, ku, ROWS_UPSAMPLE, u));
+    if (cin % 32 == 0 && (cout * u) % 32 == 0 && ku / u == 2) {
+      // split-bf16 fragments of the polyphase form (virtual rows v = co * u + r, taps k = 0, 1 <-> m = 1, 0; see add_conv)
+      DevConv& d = hm->ups.back();
+      const int rows = cout * u, Kt = ku / u;
+      PackedConv16 p16 = pack_conv_bf16(rows, rows >= 128 ? 4 : rows / 32, cin, Kt, [&](int v, int ci, int k) {
+        const int co = v / u, r = v % u, m = Kt - 1 - k;
+        return w[((size_t)ci * cout + co) * ku + m * u + r];
+      });
+      d.w16_off = (ab16.size() + 127) & ~(size_t)127;
+      ab16.resize(d.w16_off + p16.w.size());
+      std::memcpy(ab16.data() + d.w16_off, p16.w.data(), p16.w.size() * sizeof(uint16_t));
+      d.mtiles16 = p16.mtiles;
+      d.nslab16 = p16.nslab;
+    }
     ch = cout;
     hm->rb[i].resize(h.num_kernels);
     // narrow stages additionally get the packing of the one-launch MRF kernel (mrf_small.h): ResBlock1 chains
@@ -481,7 +495,10 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   const float* A = hm->arena;
   fix(hm->pre, A);
   fix(hm->post, A);
-  for (auto& c : hm->ups) fix(c, A);
+  for (auto& c : hm->ups) {
+    fix(c, A);
+    fix16(c);
+  }
   for (auto& st : hm->rb)
     for (auto& kk : st)
       for (auto& rc : kk) {
