@@ -530,7 +530,6 @@ static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t
 #define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
 #define PAIR_K(KK)                                  \
   if (p.C == 32) PAIR_LAUNCH(KK, 1, 2);             \
-  else if (p.NB == 2) PAIR_LAUNCH(KK, 2, 2);        \
   else PAIR_LAUNCH(KK, 2, 1)
   if (p.K == 3) { PAIR_K(3); }
   else if (p.K == 7) { PAIR_K(7); }

@@ -117,7 +117,7 @@ struct PairGeom {
 #ifdef MI355TTS_PAIR_SPLIT_LDS  // A/B builds: the round-2 layout (x tile and parked tile side by side)
   static constexpr int RED = XS;
 #else
-  static constexpr int RED = 4 * NB * 16 * 64;
+  static constexpr int RED = 2 * 4 * 16 * 64;  // the reduce-scatter's exchange scratch: 2 k-groups x 4 time-waves x one block
 #endif
   static constexpr int LDS = XS > RED + TS ? XS : RED + TS;
 };
@@ -135,8 +135,8 @@ __device__ __forceinline__ void pair_tile(const PairArgs& a, const int tile_x, c
   constexpr int NO = (C / 8) / 2;      // octets per k-group
   constexpr int NF4 = C * (XW / 4);
   constexpr int NE = (NF4 + 511) / 512;
-  constexpr int RED = WN * NB * 16 * 64;  // one m-block of every time-wave
-  static_assert(C * XW >= RED, "reduction scratch must fit in the x tile");
+  constexpr int RED = PairGeom<K, CB, NB>::RED;
+  static_assert(C * XW >= 2 * 4 * 16 * 64, "the exchange scratch must fit in the x tile");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -205,53 +205,54 @@ __device__ __forceinline__ void pair_tile(const PairArgs& a, const int tile_x, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   };
-  // sum the two k-groups through LDS (scratch aliases the x tile, dead by then), one
-  // m-block per round; group 0 continues with the full sums
-  auto reduce_groups = [&]() {
+  // Reduce-scatter of the two k-groups' partial tiles through LDS (scratch aliases the x tile, dead by then): a wave holds
+  // CB x NB = 2 accumulator blocks ("units": the two m-blocks at C = 64, the two column blocks at C = 32); k-group g ends up
+  // with the finished unit g — ONE exchange round instead of one reduction round per block, and BOTH k-groups run their
+  // half of the epilogue (with a reduce-to-group-0 half the waves sat out the longest memory round trips of the kernel).
+  static_assert(CB * NB == 2, "two accumulator blocks per wave: one per k-group");
+  // (the unit index is a compile-time constant everywhere: a run-time index into the accumulator array would put it in scratch)
+  floatx16& u0 = CB == 2 ? acc[0][0] : acc[0][0];
+  floatx16& u1 = CB == 2 ? acc[1][0] : acc[0][NB - 1];
+  floatx16 own;  // the finished unit of this wave
+  auto reduce_scatter = [&]() {
     float* red = xs;
+    __syncthreads();
+    if (kg == 0) {
 #pragma unroll
-    for (int mb = 0; mb < CB; ++mb) {
-      __syncthreads();
-      if (kg == 1) {
+      for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = u1[r];
+    } else {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+      for (int r = 0; r < 16; ++r) red[((4 + wn) * 16 + r) * 64 + lane] = u0[r];
+    }
+    __syncthreads();
+    if (kg == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((wn * NB + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
-      }
-      __syncthreads();
-      if (kg == 0) {
+      for (int r = 0; r < 16; ++r) own[r] = u0[r] + red[((4 + wn) * 16 + r) * 64 + lane];
+    } else {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mb][nb][r] += red[((wn * NB + nb) * 16 + r) * 64 + lane];
-      }
+      for (int r = 0; r < 16; ++r) own[r] = u1[r] + red[(wn * 16 + r) * 64 + lane];
     }
   };
+  const int mb_own = CB == 2 ? kg : 0, nb_own = CB == 2 ? 0 : kg;  // the unit this wave finishes
 
   // ---- phase 1: conv1 (dilation d) on T1 columns
   zero_acc();
   pair_mfma_phase<K, CB, NB, NO>(acc, wq1, kg, xs + half * XW + shift + wn * (NB * 32) + col, XW, a.dil);
-  reduce_groups();
-  if (kg == 0) {
+  reduce_scatter();
+  {
     // park lrelu(conv1 + bias); columns outside the sequence are conv2's ZERO padding
+    float bb[16];
 #pragma unroll
-    for (int mb = 0; mb < CB; ++mb) {
-      float bb[16];
+    for (int r = 0; r < 16; ++r) bb[r] = a.b1[mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+    const int jj = (wn * NB + nb_own) * 32 + col;
+    const int g = gt0 + jj;
+    const bool inside = g >= 0 && g < L;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bb[r] = a.b1[mb * 32 + (r & 3) + 8 * (r >> 2) + rbase];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int jj = (wn * NB + nb) * 32 + col;
-        const int g = gt0 + jj;
-        const bool inside = g >= 0 && g < L;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-          float v = acc[mb][nb][r] + bb[r];
-          v = v > 0.f ? v : v * slope;
-          ts[row * TW + jj] = inside ? v : 0.f;
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+      float v = own[r] + bb[r];
+      v = v > 0.f ? v : v * slope;
+      ts[row * TW + jj] = inside ? v : 0.f;
     }
   }
   __syncthreads();
@@ -259,38 +260,33 @@ __device__ __forceinline__ void pair_tile(const PairArgs& a, const int tile_x, c
   // ---- phase 2: conv2 (dilation 1) on the parked tile
   zero_acc();
   pair_mfma_phase<K, CB, NB, NO>(acc, wq2, kg, ts + half * TW + wn * (NB * 32) + col, TW, 1);
-  reduce_groups();
-  if (kg != 0) return;
+  reduce_scatter();
   // ---- epilogue: + bias + residual, batched loads from clamped addresses
-#pragma unroll
-  for (int mb = 0; mb < CB; ++mb) {
+  {
     float bb[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bb[r] = a.b2[mb * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+    for (int r = 0; r < 16; ++r) bb[r] = a.b2[mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+    const int jj = (wn * NB + nb_own) * 32 + col;
+    const int g = j0 + jj;
+    const bool tok = jj < T2 && g < L;
+    const int gc = g < L ? g : L - 1;
+    const float* rb = xb + gc;
+    float* yb = a.y + (long long)b * a.bs + gc;
+    float rv[16], v[16];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int jj = (wn * NB + nb) * 32 + col;
-      const int g = j0 + jj;
-      const bool tok = jj < T2 && g < L;
-      const int gc = g < L ? g : L - 1;
-      const float* rb = xb + gc;
-      float* yb = a.y + (long long)b * a.bs + gc;
-      float rv[16], v[16];
+    for (int r = 0; r < 16; ++r) rv[r] = rb[(mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] = rb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
+    for (int r = 0; r < 16; ++r) v[r] = (own[r] + bb[r] + rv[r]) * a.alpha;
+    if (a.accum) {
+      float ov[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = (acc[mb][nb][r] + bb[r] + rv[r]) * a.alpha;
-      if (a.accum) {
-        float ov[16];
+      for (int r = 0; r < 16; ++r) ov[r] = yb[(mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = yb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += ov[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (tok) yb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld] = v[r];
+      for (int r = 0; r < 16; ++r) v[r] += ov[r];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (tok) yb[(mb_own * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld] = v[r];
   }
 }
 
