@@ -51,3 +51,24 @@ def test_single_short_utterance(emu_engine, narrow):
     f32, _ = emu_engine.hifigan_infer(v, emu_engine.mel_from_numpy(melin))
     ref = hifi_gan_np.hifigan_infer(sd, hp, melin[0])
     assert np.sqrt(np.mean((f32[0, : ref.shape[0]] - ref) ** 2)) < 1e-5
+
+
+def test_two_dilation_steps_and_the_fallback_for_other_taps(emu_engine):
+    """Chains of two dilation steps run on the fused kernels (`nsteps` is a run-time value); tap sets other than (3, 7, 11) —
+    and receptive fields wider than the staged halo — fall back to the conv-by-conv schedule.  Both against the oracle."""
+    rng = np.random.default_rng(31)
+    for hp in (
+        HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=32, num_mels=16,
+                          resblock_dilation_sizes=((1, 5), (3, 1), (2, 4))),
+        HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=32, num_mels=16,
+                          resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12))),
+        HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=32, num_mels=16,
+                          resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 5, 5))),  # k = 11 chain: half-width 70 > 64
+    ):
+        sd = synthetic.make_hifigan_state_dict(hp, seed=12)
+        v = emu_engine.load_hifigan(hp, sd)
+        melin = (rng.standard_normal((1, hp.num_mels, 40)) * 2).astype(np.float32)
+        f32, _ = emu_engine.hifigan_infer(v, emu_engine.mel_from_numpy(melin))
+        ref = hifi_gan_np.hifigan_infer(sd, hp, melin[0])
+        assert np.sqrt(np.mean((f32[0, : ref.shape[0]] - ref) ** 2)) < 1e-5
+        emu_engine.unload(v)
