@@ -30,6 +30,9 @@
 #define MI355TTS_ABLATE(a, bit) 0
 #endif
 
+#ifndef CONV_STAMP
+#define CONV_STAMP(n)  // phase stamps of tools/probe/glow_conv_bench.hip
+#endif
 #ifndef MI355TTS_ARING
 #define MI355TTS_ARING 3  // depth of the A-fragment register ring (steps in flight + 1)
 #endif
@@ -342,6 +345,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
   // prologue: everything the first MFMA needs goes out in ONE batch of loads — the
   // first activation chunk, the first weight fragments (cold in L2: a layer's weights are
   // read for the first time here), then the second chunk — before anything is waited for
+  CONV_STAMP(0);
   gload(0, preA);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -350,8 +354,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
   if constexpr (!PD1) {
     if (nchunks > 1) gload(1, preB);
   }
+  CONV_STAMP(1);
   lstore(0, 0, preA);
   __syncthreads();
+  CONV_STAMP(2);
 
   const int b_off = (lane >> 5) * XW + wn * (NB * 32) + (lane & 31) + (PA - a.pad);
 
@@ -446,6 +452,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
     }
   }
 
+  CONV_STAMP(3);
   // ---------------------------------------------------------------- k-group reduction
   // C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   constexpr int R = 16 / KS;  // accumulator registers per 32x32 block that one k-group ends up owning
@@ -532,6 +539,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
     if (kg > 0) return;
   }
 
+  CONV_STAMP(4);
   // ---------------------------------------------------------------- epilogue
   // Loads (bias / residual / accumulate) go out in batches from clamped,
   // always-valid addresses under wave-uniform conditions only; lanes outside the
@@ -801,6 +809,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && ((NB == 1
   }
   xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
   conv_tile<K, CI_C, MB, NB, WN, KS, HALO, EPI, WM>(a, tile_x, tile_y, blockIdx.z, xs);
+  CONV_STAMP(5);
 }
 
 // The MRF chains of a HiFi-GAN stage (hifi_gan/models.py:191-197) run convs of the SAME geometry

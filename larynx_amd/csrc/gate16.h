@@ -1,0 +1,149 @@
+// The WaveNet gate conv of the GlowTTS decoder (glow_tts/layers.py:138-162: in_layers[i], k taps, H -> 2H rows, then
+// tanh(first half) * sigmoid(second half), glow_tts/utils.py:31-38) on 16-row x 32-column tiles.
+//
+// Why a second tile for one layer type: at batch 1 the decoder's time axis is ~312 columns.  conv_mfma.h's smallest
+// tile (32 virtual rows x 32 columns, 8 k-groups) yields 12 x 10 = 120 workgroups for H = 192 — under half of the 256
+// CUs — and each of them holds 480 v_mfma_f32_32x32x2 on ONE CU's four matrix pipes: 7680 cycles per SIMD, 3.2-3.8 us,
+// which is what its main loop measures (4.9 of the launch's 9.1 us; tools/probe/glow_conv_bench.hip).  More k-groups
+// do not help (the pipes are the CU's), smaller tiles do: v_mfma_f32_16x16x4_f32 has the same FLOP rate per pipe, so a
+// 16-row tile = 8 gate channels (8 tanh rows + their 8 sigmoid rows) x 32 columns is 240 workgroups of half the work.
+//
+// One workgroup = 8 waves = 8 k-groups.  All Cin input channels of the tile's 32 (+ halo) columns are staged once
+// (f32, [channel][48 columns]: the stride puts the four K-lanes of a B fragment in four disjoint bank groups);
+// k-group g takes the 4-channel groups g, g + 8, ... with all their taps, its A fragments (pre-packed per lane, one
+// dword per MFMA) all requested at entry; two accumulators (column blocks) per wave make consecutive MFMAs
+// independent.  The 8 partial tiles meet in LDS, where thread (channel i, column n) finds its tanh and sigmoid rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi355tts {
+
+#ifndef GATE_STAMP
+#define GATE_STAMP(n)
+#endif
+
+typedef float gate_floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int GATE16_XW = 48;       // staged columns per channel row (32 + up to 16 of halo and alignment)
+constexpr int GATE16_MAX_CIN = 512;  // 96 KB of LDS
+
+struct Gate16Args {
+  const float* x;  // [B][Cin][x_ld]
+  long long x_bs;
+  int x_ld;
+  const int* len;  // valid columns per batch row: len ? len[b] * len_mul : len_const (input and output)
+  int len_mul, len_const;
+  const float* w;     // pack_gate16: [row tile][k-group][J][K][64 lanes]
+  const float* bias;  // [row tile][16]: 8 tanh-row biases, 8 sigmoid-row biases
+  int Cin, half;      // input channels, gate channels (= output rows)
+  int dil, pad;
+  float* y;  // [B][half][y_ld]
+  long long y_bs;
+  int y_ld;
+};
+
+// K taps, J = 4-channel groups per k-group (Cin <= 32 J)
+template <int K, int J>
+__global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
+  __shared__ float xs[(32 * J * GATE16_XW > 4096) ? 32 * J * GATE16_XW : 4096];  // [32 J][48]; afterwards the partial tiles [8][2][4][64]
+  const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
+  const int b = blockIdx.z;
+  const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
+  // ragged batch: a row deals only its own tiles (conv_mfma.h, row_tiles); XCD x takes a contiguous run of them, time
+  // tile fastest: an XCD's L2 then holds 1/8 of the weights (the bigger operand here) and the whole input
+  const int gx = (L + 31) / 32, gy = gridDim.y;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (lin >= gx * gy) return;
+  int tx, ty;
+  {
+    const int n = gx * gy, xcd = lin & 7, slot = lin >> 3, q = n >> 3, r = n & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tx = id % gx;
+    ty = id / gx;
+  }
+  const int t0 = tx * 32;
+  constexpr int CP = 32 * J;  // staged channel rows
+  constexpr int XW = GATE16_XW, XW4 = XW / 4;
+  const int PA = (a.pad + 3) & ~3;
+
+  // ---- every load whose address is known at entry: the A fragments of this k-group ...
+  float af[J][K];
+  {
+    const float* wp = a.w + ((long long)(ty * 8 + kg) * (J * K)) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int k = 0; k < K; ++k) af[j][k] = wp[(j * K + k) * 64];
+  }
+  // ... and the activation tile (16 bytes per lane, clamped addresses, zeroed by select)
+  constexpr int NF4 = CP * XW4, NE = (NF4 + 511) / 512;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  float4 pre[NE];
+  GATE_STAMP(0);
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 512 * i;
+    const int row = e / XW4, f = e - row * XW4;
+    const int c0 = t0 - PA + 4 * f;
+    const int ci = row < a.Cin ? row : a.Cin - 1;
+    pre[i] = *reinterpret_cast<const float4*>(xb + (long long)ci * a.x_ld + (c0 < 0 ? 0 : (c0 > a.x_ld - 4 ? a.x_ld - 4 : c0)));
+  }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 512 * i;
+    const int row = e / XW4, f = e - row * XW4;
+    const int c0 = t0 - PA + 4 * f;
+    const bool rok = row < a.Cin;
+    float4 v = pre[i];
+    v.x = (rok && c0 >= 0 && c0 < L) ? v.x : 0.f;
+    v.y = (rok && c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+    v.z = (rok && c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+    v.w = (rok && c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+    if (e < NF4) reinterpret_cast<float4*>(xs)[e] = v;
+  }
+  __syncthreads();
+  GATE_STAMP(1);
+
+  // ---- main loop: B fragment lane (n = lane & 15, kq = lane >> 4) = x[4 g + kq][t0 + n + k dil - pad]
+  gate_floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* bp = xs + (4 * kg + (lane >> 4)) * XW + (lane & 15) + (PA - a.pad);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float* p = bp + (32 * j) * XW + k * a.dil;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[16], acc1, 0, 0, 0);
+      }
+    }
+  }
+  GATE_STAMP(2);
+  __syncthreads();
+  // ---- the k-groups' partial tiles: red[kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
+  {
+    float* red = xs + (kg * 2) * 256 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[r * 64] = acc0[r];
+      red[256 + r * 64] = acc1[r];
+    }
+  }
+  __syncthreads();
+  GATE_STAMP(3);
+  if (tid < 256) {
+    const int i = tid >> 5, n = tid & 31;  // gate channel 8 ty + i, column t0 + n
+    const int src = (n >> 4) * 256 + (i & 3) * 64 + (i >> 2) * 16 + (n & 15);
+    float v0 = a.bias[ty * 16 + i], v1 = a.bias[ty * 16 + 8 + i];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      v0 += xs[g * 512 + src];
+      v1 += xs[g * 512 + src + 32];  // row i + 8: two 16-lane groups further
+    }
+    const int c = ty * 8 + i, t = t0 + n;
+    if (c < a.half && t < L) a.y[(long long)b * a.y_bs + (long long)c * a.y_ld + t] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
+  }
+  GATE_STAMP(4);
+}
+
+}  // namespace mi355tts

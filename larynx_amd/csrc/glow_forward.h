@@ -193,14 +193,20 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       ProfScope ps(ctx, w, KC_SMALL, 0);
       const dim3 ag((Pmax + 31) / 32, nh, B);
       const int dkh = H / nh;
-#define ATT_LAUNCH(NK)                                                                                                   \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK>), ag, dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,     \
+#define ATT_LAUNCH_X(NK, X)                                                                                              \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK, X>), ag, dim3(512), 0, s, qkv, 3 * bsH, P, d_len, H, nh,  \
                      h.window_size, A + L.ek, A + L.ev, t2, bsH, P)
+#define ATT_LAUNCH(NK)                                                                                                   \
+  do {                                                                                                                   \
+    if (dkh == 2 * NK) ATT_LAUNCH_X(NK, true);                                                                           \
+    else ATT_LAUNCH_X(NK, false);                                                                                        \
+  } while (0)
       if (Pmax <= ATTM_MAXP && dkh <= 32) ATT_LAUNCH(16);
       else if (Pmax <= ATTM_MAXP && dkh <= 64) ATT_LAUNCH(32);
       else if (Pmax <= ATTM_MAXP && dkh <= 96) ATT_LAUNCH(48);
       else if (Pmax <= ATTM_MAXP) ATT_LAUNCH(64);
 #undef ATT_LAUNCH
+#undef ATT_LAUNCH_X
       else
         hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
                            h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
@@ -367,7 +373,13 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
       a.half = H;
-      CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
+      if (B == 1 && dec_host_len >= 0) {  // the length is known on the host: no device length array to chase
+        a.in_len = a.out_len = nullptr;
+        a.in_const = a.out_const = dec_host_len;
+      }
+      const int g16 = run_gate16(ctx, w, Bk.in[j], a, B, F2max, KC_GLOW_DEC_CONV, s);
+      if (g16 < 0) return g16;
+      if (g16 == 1) CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       if (j < h.n_block_layers - 1) {
         r.res = hbuf;  // x = x + res_skip[:H]

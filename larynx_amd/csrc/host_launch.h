@@ -623,6 +623,48 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   return 0;
 }
 
+// ---- the WaveNet gate conv on 16-row tiles (gate16.h).  Returns 1 when this conv / launch is not one the kernel takes
+// (the caller then launches the 32-row tile), 0 when launched, < 0 on error.  `a` is the ConvArgs of the same launch.
+static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvArgs& a, int B, int n_max, int cls, hipStream_t s) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GATE16"); return e && std::atoi(e) != 0; }();
+  // more 32-row tiles than this and the launch fills the chip either way (measured: profiles/NOTES.md)
+  static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_GATE16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
+  if (off || !ctx->gate16.load() || !c.g16_J || n_max <= 0) return 1;
+  const int PA = (a.pad + 3) & ~3;
+  if ((PA - a.pad) + 31 + (c.K - 1) * a.dil >= GATE16_XW || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
+  const int gx = (n_max + 31) / 32, gy = (a.half + 7) / 8;
+  if ((long long)gx * ((a.half + 15) / 16) * B > max_tiles) return 1;
+  Gate16Args g;
+  std::memset(&g, 0, sizeof(g));
+  g.x = a.x; g.x_bs = a.x_bs; g.x_ld = a.x_ld;
+  g.len = a.in_len; g.len_mul = a.in_mul; g.len_const = a.in_const;
+  g.w = c.g16_w; g.bias = c.g16_b; g.Cin = c.Cin; g.half = a.half; g.dil = a.dil; g.pad = a.pad;
+  g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld;
+  ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B, s);
+  const dim3 grid(gx, gy, B);
+#define GATE16_LAUNCH(KK, JJ) hipLaunchKernelGGL(HIP_KERNEL_NAME(gate16_kernel<KK, JJ>), grid, dim3(512), 0, s, g)
+#define GATE16_J(KK)                      \
+  switch (c.g16_J) {                      \
+    case 1: GATE16_LAUNCH(KK, 1); break;  \
+    case 2: GATE16_LAUNCH(KK, 2); break;  \
+    case 3: GATE16_LAUNCH(KK, 3); break;  \
+    case 4: GATE16_LAUNCH(KK, 4); break;  \
+    case 6: GATE16_LAUNCH(KK, 6); break;  \
+    case 8: GATE16_LAUNCH(KK, 8); break;  \
+    default: return 1;                    \
+  }
+  if (c.K == 3) {
+    GATE16_J(3)
+  } else if (c.K == 5) {
+    GATE16_J(5)
+  } else {
+    return 1;
+  }
+#undef GATE16_J
+#undef GATE16_LAUNCH
+  return 0;
+}
+
 static ConvArgs base_args(const float* x, long long x_bs, int x_ld, const int* in_len, int in_mul, float* y, long long y_bs,
                           int y_ld, const int* out_len, int out_mul, int dil, int pad) {
   ConvArgs a;

@@ -36,6 +36,11 @@ struct DevConv {
   size_t w16_off = 0;  // offset (uint16 elements) into the model's bf16 arena
   const void* w16 = nullptr;
   int mtiles16 = 0, nslab16 = 0;
+  // the 16-row-tile packing of a WaveNet gate conv (gate16.h), present when its shape is one the kernel is built for
+  size_t g16_w_off = 0, g16_b_off = 0;
+  const float* g16_w = nullptr;
+  const float* g16_b = nullptr;
+  int g16_J = 0;  // 4-channel groups per k-group; 0 = no such packing
 };
 
 struct ArenaBuilder {
@@ -107,6 +112,22 @@ static DevConv add_conv(ArenaBuilder& ab, const float* w, const float* bias, int
   d.w_off = ab.add(p.w);
   if (d.has_bias) d.b_off = ab.add(p.bias);
   return d;
+}
+
+// gate16.h instantiations: taps x channel groups per k-group (Cin <= 32 J)
+static bool gate16_shape_ok(int K, int Cin) {
+  const int J = (Cin + 31) / 32;
+  return (K == 3 || K == 5) && (J == 1 || J == 2 || J == 3 || J == 4 || J == 6 || J == 8);
+}
+// the second packing of a WaveNet gate conv w[2*half][Cin][K] (add_conv(..., ROWS_PAIR, half) made the first)
+static void add_gate16(ArenaBuilder& ab, DevConv& d, const float* w, const float* bias, int half, int Cin, int K) {
+  if (!gate16_shape_ok(K, Cin)) return;
+  PackedGate16 p = pack_gate16(
+      half, Cin, K, [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
+      bias != nullptr);
+  d.g16_J = p.J;
+  d.g16_w_off = ab.add(p.w);
+  d.g16_b_off = ab.add(p.bias);
 }
 
 struct Blob {

@@ -29,6 +29,7 @@
 #include "conv_bf16.h"
 #include "resblock_pair_bf16.h"
 #include "mrf_small.h"
+#include "gate16.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -161,6 +162,10 @@ static int upload_arena(mi355tts_ctx* ctx, ArenaBuilder& ab, float** dev) {
 static void fix(DevConv& c, const float* arena) {
   c.w = arena + c.w_off;
   c.bias = c.has_bias ? arena + c.b_off : nullptr;
+  if (c.g16_J) {
+    c.g16_w = arena + c.g16_w_off;
+    c.g16_b = arena + c.g16_b_off;
+  }
 }
 
 extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams* hp, const float* blob, int64_t numel,
@@ -296,6 +301,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
       TAKE(wr, rl + ".weight", (int64_t)rsn * H);
       TAKE(br, rl + ".bias", rsn);
       B.in.push_back(add_conv(ab, wi, bi, 2 * H, H, h.kernel_size_dec, ROWS_PAIR, H));
+      add_gate16(ab, B.in.back(), wi, bi, H, H, h.kernel_size_dec);
       B.rs.push_back(add_conv(ab, wr, br, rsn, H, 1, ROWS_PLAIN));
     }
     TAKE(we, cp + ".end.weight", (int64_t)C * H);
@@ -1078,6 +1084,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "mrf_small") == 0) {
     ctx->mrf_small = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "gate16") == 0) {
+    ctx->gate16 = value != 0;
     return 0;
   }
   if (std::strcmp(name, "mrf_group") == 0) {

@@ -265,12 +265,19 @@ constexpr int ATTM_MAXP = 768;
 constexpr int ATTM_PS = ATTM_MAXP + 1;  // odd row stride: conflict-free column reads
 typedef float att_floatx16 __attribute__((ext_vector_type(16)));
 
-template <int NK>  // MFMA k-steps covering the head dimension: 2*NK >= dk
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
+#ifndef ATT_STAMP
+#define ATT_STAMP(n)
+#endif
+// The launch is a latency chain on a handful of workgroups (8 at P = 120), and at one or two waves per SIMD its
+// time is the instruction count of the slowest wave (phase stamps: profiles/NOTES.md).  So: eight waves share
+// every phase, nothing is masked that is never read, addresses advance by one add per load, and every global
+// load whose address is known at entry is issued at entry.  EXACT: dk == 2*NK (no channel clamps at all).
+template <int NK, bool EXACT>  // MFMA k-steps covering the head dimension: 2*NK >= dk
+__global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
                                                              int nheads, int window, const float* ek, const float* ev,
                                                              float* out, long long out_bs, int out_ld) {
   __shared__ float S[32 * ATTM_PS];
-  __shared__ float vs[ATT_MAXDK * 65];
+  __shared__ float vs[ATT_MAXDK * 65];  // V chunk [channel][64 keys]; afterwards the k-split partial outputs
   __shared__ float relS[32 * 33];
   __shared__ float evs[ATT_MAXW * ATT_MAXDK];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -278,142 +285,215 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, l
   const int P = len[b];
   const int i0 = blockIdx.x * 32;
   if (i0 >= P) return;
-  const int dk = H / nheads;
+  const int dk = EXACT ? 2 * NK : H / nheads;
   const int nrel = 2 * window + 1;
   const float scale = rsqrtf((float)dk);
   const float* q = qkv + (long long)b * bs + (long long)(h * dk) * ld;
   const float* k = q + (long long)H * ld;
   const float* v = k + (long long)H * ld;
   const int nkb = (P + 31) / 32;  // key blocks
+  const int jpad = nkb * 32;
   const int col = lane & 31, half = lane >> 5;
   const int rbase = 4 * half;
   const int iq = min(i0 + col, P - 1);  // this lane's query column for A operands (clamped)
 
-  for (int e = threadIdx.x; e < ATT_MAXW * ATT_MAXDK; e += 256) {
-    const int rr = e / ATT_MAXDK, c = e - rr * ATT_MAXDK;
-    evs[e] = (rr < nrel && c < dk) ? ev[rr * dk + c] : 0.f;  // consumed after several barriers
-  }
+  // V chunk staging: thread t owns key column t & 63 of channels (t >> 6) + 8 u
+  constexpr int VU = ATT_MAXDK / 8;
+  const int vj = threadIdx.x & 63, vc0 = threadIdx.x >> 6;
+  float tv[VU];
+  auto v_fetch = [&](int j0) __attribute__((always_inline)) {
+    const float* p = v + (long long)vc0 * ld + min(j0 + vj, P - 1);
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      if (vc0 + 8 * u < dk) tv[u] = *p;  // wave-uniform
+      p += 8 * ld;
+    }
+  };
+  auto v_park = [&](int j0) __attribute__((always_inline)) {
+    const bool ok = j0 + vj < P;
+#pragma unroll
+    for (int u = 0; u < VU; ++u)
+      if (vc0 + 8 * u < dk) vs[(vc0 + 8 * u) * 65 + vj] = ok ? tv[u] : 0.f;
+  };
+
   // ---- phase 1: S[i][j] = scale * q_i . k_j  (M = queries, N = keys, K-dim = channels).
-  // The query fragments are loaded once and stay in registers; every key block (and
-  // one extra block whose "keys" are the 2w+1 relative-position embeddings,
-  // attentions.py:228-234) costs one batch of loads + NK MFMAs.
-  float av[NK];
-#pragma unroll
-  for (int u = 0; u < NK; ++u) {
-    const int c = 2 * u + half;
-    const float t = q[(long long)(c < dk ? c : dk - 1) * ld + iq];
-    av[u] = c < dk ? t : 0.f;
+  // One key block per wave per round; one extra block's "keys" are the 2w+1 relative-position
+  // embeddings (attentions.py:228-234) — its columns >= 2w+1 hold junk that is never read.
+  v_fetch(0);
+  for (int e = threadIdx.x; e < nrel * ATT_MAXDK; e += 512) {
+    const int rr = e >> 7, c = e & (ATT_MAXDK - 1);
+    evs[e] = c < dk ? ev[rr * dk + c] : 0.f;  // consumed after several barriers
   }
-  for (int nb = wave; nb <= nkb; nb += 4) {
-    const bool band = nb == nkb;
-    const int jk = min(nb * 32 + col, P - 1);
-    const int rr = col < nrel ? col : nrel - 1;
-    float bv[NK];
+  ATT_STAMP(1);
+  if (wave <= nkb) {
+    float av[NK];
+    {
+      // channel c = 2u + half; past dk (only when !EXACT) the pointer stops at the lane's last real channel and the
+      // value is dropped by select: no branches, no second address stream
+      const float* p = q + (long long)min(half, dk - 1) * ld + iq;
 #pragma unroll
-    for (int u = 0; u < NK; ++u) {
-      const int c = 2 * u + half;
-      const int cc = c < dk ? c : dk - 1;
-      const float t = band ? ek[rr * dk + cc] : k[(long long)cc * ld + jk];
-      bv[u] = (c < dk && (!band || col < nrel)) ? t : 0.f;
+      for (int u = 0; u < NK; ++u) {
+        const float t = *p;
+        av[u] = (EXACT || 2 * u + half < dk) ? t : 0.f;
+        p += (EXACT || 2 * u + 2 + half < dk) ? 2 * ld : 0;
+      }
     }
-    att_floatx16 acc;
+    for (int nb = wave; nb <= nkb; nb += 8) {
+      const bool band = nb == nkb;
+      const int jk = min(nb * 32 + col, P - 1);
+      const int rr = col < nrel ? col : nrel - 1;
+      const int h0 = min(half, dk - 1);
+      const float* p = band ? ek + rr * dk + h0 : k + (long long)h0 * ld + jk;
+      const long long st = band ? 2 : 2 * (long long)ld;
+      float bv[NK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int u = 0; u < NK; ++u) {
+        const float t = *p;
+        bv[u] = (EXACT || 2 * u + half < dk) ? t : 0.f;
+        p += (EXACT || 2 * u + 2 + half < dk) ? st : 0;
+      }
+      att_floatx16 acc;
 #pragma unroll
-    for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    const int j = nb * 32 + col;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + rbase;
-      if (band) relS[i * 33 + col] = acc[r] * scale;
-      else S[i * ATTM_PS + j] = (j < P) ? acc[r] * scale : -3.0e38f;
+      for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      float* dst = band ? relS + rbase * 33 + col : S + rbase * ATTM_PS + nb * 32 + col;
+      const int rs = band ? 33 : ATTM_PS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * rs] = acc[r] * scale;  // keys >= P: never read
     }
   }
+  ATT_STAMP(3);
+  v_park(0);
+  if (64 < jpad) v_fetch(64);  // in flight across the band add and the softmax
   __syncthreads();
+  ATT_STAMP(4);
   // ---- relative-key band: S[i][i+r-w] += scale * q_i . Ek[r]
-  for (int r = threadIdx.x >> 5; r < nrel; r += 8) {
+  for (int r = threadIdx.x >> 5; r < nrel; r += 16) {
     const int i = threadIdx.x & 31;
     const int gi = i0 + i;
     const int j = gi + r - window;
     if (gi < P && j >= 0 && j < P) S[i * ATTM_PS + j] += relS[i * 33 + r];
   }
   __syncthreads();
-  // ---- softmax over keys, one wave per row
-  for (int i = wave; i < 32; i += 4) {
-    float* row = S + i * ATTM_PS;
-    float mx = -3.0e38f;
-    for (int j = lane; j < P; j += 64) mx = fmaxf(mx, row[j]);
-    mx = wave_max(mx);
-    float den = 0.f;
-    for (int j = lane; j < P; j += 64) {
-      const float e = expf(row[j] - mx);
-      row[j] = e;
-      den += e;
+  ATT_STAMP(5);
+  // ---- softmax over keys: 16 lanes per row, the four rows of a wave at once (reductions are four xor steps);
+  // keys P..jpad get the exact zero weight the reference's -1e4 fill underflows to.  Up to 256 keys a lane's
+  // 16 scores stay in registers between the three passes.
+  {
+    const int sub = lane >> 4, l16 = lane & 15;
+    float* row = S + (wave * 4 + sub) * ATTM_PS;
+    if (P <= 256) {
+      float e[16];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        e[t] = (l16 + 16 * t < P) ? row[l16 + 16 * t] : -3.0e38f;
+        mx = fmaxf(mx, e[t]);
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+      float den = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        e[t] = (l16 + 16 * t < P) ? expf(e[t] - mx) : 0.f;
+        den += e[t];
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) den += __shfl_xor(den, m);
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (16 * t < jpad) row[l16 + 16 * t] = e[t] * inv;  // uniform; jpad is a multiple of 32
+    } else {
+      float mx = -3.0e38f;
+      for (int j = l16; j < P; j += 16) mx = fmaxf(mx, row[j]);
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+      float den = 0.f;
+      for (int j = l16; j < P; j += 16) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        den += e;
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) den += __shfl_xor(den, m);
+      const float inv = 1.0f / den;
+      for (int j = l16; j < jpad; j += 16) row[j] = (j < P) ? row[j] * inv : 0.f;
     }
-    den = wave_sum(den);
-    const float inv = 1.0f / den;
-    for (int j = lane; j < nkb * 32; j += 64) row[j] = (j < P) ? row[j] * inv : 0.f;
   }
   __syncthreads();
-  // ---- phase 2: O^T[c][i] = sum_j v[c][j] p[i][j]   (M = channels, N = queries, K-dim = keys)
-  const int ncb = (dk + 31) / 32;
+  ATT_STAMP(6);
+  // ---- phase 2: O^T[c][i] = sum_j v[c][j] p[i][j]   (M = channels, N = queries, K-dim = keys).  A wave is one
+  // (32-channel block, key slice) unit: the 8-key groups of a chunk are dealt round-robin to the nks slices.
+  const int ncb = (dk + 31) / 32;           // <= 4
+  const int nks = ncb == 3 ? 2 : 8 / ncb;   // 8, 4, 2, 2 slices: ncb * nks <= 8 waves
+  const int cb = wave % ncb, ks = wave / ncb;
+  const bool unit = ks < nks;
   att_floatx16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int j0 = 0; j0 < nkb * 32; j0 += 64) {
-    __syncthreads();
-    for (int e0 = threadIdx.x; e0 < dk * 64; e0 += 8 * 256) {  // 8 loads in flight per thread
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * 256;
-        const int c = min(e >> 6, dk - 1), jj = e & 63;
-        t[u] = v[(long long)c * ld + min(j0 + jj, P - 1)];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * 256;
-        const int c = e >> 6, jj = e & 63;
-        if (c < dk) vs[c * 65 + jj] = (j0 + jj < P) ? t[u] : 0.f;
-      }
-    }
-    __syncthreads();
-    if (wave < ncb) {
-      const int c = min(wave * 32 + col, dk - 1);
-      const int jn = min(64, nkb * 32 - j0);
-      for (int jj = 0; jj < jn; jj += 8) {  // jn is a multiple of 32
-        float av[4], bv[4];
+  for (int j0 = 0; j0 < jpad; j0 += 64) {
+    if (unit) {
+      const int cl = cb * 32 + col;
+      const float* va = vs + min(cl, dk - 1) * 65 + half;
+      const float* pb = S + col * ATTM_PS + j0 + half;
+      const int jn = min(64, jpad - j0);
+      for (int jj = 8 * ks; jj < jn; jj += 8 * nks) {  // jn is a multiple of 32
+        float a4[4], b4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          av[u] = (wave * 32 + col < dk) ? vs[c * 65 + jj + 2 * u + half] : 0.f;
-          bv[u] = S[col * ATTM_PS + j0 + jj + 2 * u + half];
+          a4[u] = (EXACT || cl < dk) ? va[jj + 2 * u] : 0.f;
+          b4[u] = pb[jj + 2 * u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], acc, 0, 0, 0);
       }
     }
+    if (j0 + 64 < jpad) {  // uniform over the workgroup
+      __syncthreads();
+      v_park(j0 + 64);
+      if (j0 + 128 < jpad) v_fetch(j0 + 128);
+      __syncthreads();
+    }
   }
-  // (dk <= 128 = 4 channel blocks, one per wave)
-  if (wave >= ncb) return;
-  // ---- relative values on the band + store: out[c][i]      (attentions.py:246-253)
-  // (Ev was staged into LDS at kernel start: no dependent global loads here)
-  const int gi = i0 + col;  // this lane's query
-  float pband[ATT_MAXW];
-#pragma unroll
-  for (int rr = 0; rr < ATT_MAXW; ++rr) {
-    const int j = gi + rr - window;
-    const bool ok = rr < nrel && j >= 0 && j < P;
-    pband[rr] = ok ? S[col * ATTM_PS + (j < 0 ? 0 : (j >= P ? P - 1 : j))] : 0.f;
+  // the relative values on the band (attentions.py:246-253) are one more K-block of the same GEMM:
+  // O^T[c][i] += sum_r Ev[r][c] p[i][i+r-w]; the last slice, which has the fewest key groups, takes it
+  if (unit && ks == nks - 1) {
+    const int cl = cb * 32 + col;
+    const int gi = i0 + col;
+    for (int u = 0; 2 * u < nrel; ++u) {
+      const int rr = 2 * u + half;
+      const int j = gi + rr - window;
+      const float a = (rr < nrel && cl < dk) ? evs[rr * ATT_MAXDK + cl] : 0.f;
+      const float p = (rr < nrel && j >= 0 && j < P && gi < P) ? S[col * ATTM_PS + j] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p, acc, 0, 0, 0);
+    }
   }
+  ATT_STAMP(7);
+  // ---- the slices' partial tiles go through LDS as [slice][channel][query] (over the dead V chunk) ...
+  __syncthreads();
+  float* red = vs;  // nks * ncb * 32 * 32 floats <= 8192 <= ATT_MAXDK * 65
+  if (unit) {
+    float* dst = red + ((ks * ncb + cb) * 32 + rbase) * 32 + col;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int c = wave * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-    const int cc = c < dk ? c : dk - 1;
-    float o = acc[r];
-#pragma unroll
-    for (int rr = 0; rr < ATT_MAXW; ++rr) o += pband[rr] * evs[rr * ATT_MAXDK + cc];
-    if (c < dk && gi < P) out[(long long)b * out_bs + (long long)(h * dk + c) * out_ld + gi] = o;
+    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
   }
+  __syncthreads();
+  // ---- ... and thread t sums and stores channels (t >> 5) + 16 m of query t & 31, lanes along time
+  {
+    const int i = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int gi = i0 + i;
+    if (gi >= P) return;
+    float* ob = out + (long long)b * out_bs + (long long)(h * dk) * out_ld + gi;
+    for (int c = cg; c < dk; c += 16) {
+      const int blk = c >> 5, cl = c & 31;
+      float o = 0.f;
+      for (int s = 0; s < nks; ++s) o += red[((s * ncb + blk) * 32 + cl) * 32 + i];
+      ob[(long long)c * out_ld] = o;
+    }
+  }
+  ATT_STAMP(8);
 }
 
 // G9a: durations.  w = exp(logw)*length_scale, w_ceil = ceil(w); cum = inclusive

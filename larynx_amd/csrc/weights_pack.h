@@ -133,4 +133,39 @@ inline std::vector<float> pack_mrf8_conv(int K, WGet wget) {
   return p;
 }
 
+// A fragments and biases for gate16_kernel (gate16.h): the WaveNet gate conv w[2*half][Cin][K] on 16-row tiles.  Row
+// tile p = gate channels 8p .. 8p+7: tile rows 0-7 are their tanh rows (w row c), rows 8-15 their sigmoid rows (w row
+// half + c).  k-group g of 8 takes the 4-channel groups g + 8 j (j < J); lane (m = l & 15, kq = l >> 4) of its step
+// (j, tap) holds W[row m][4 (g + 8 j) + kq][tap] — the A operand of v_mfma_f32_16x16x4_f32.  Zero past half / Cin.
+struct PackedGate16 {
+  std::vector<float> w;     // [ptiles][8][J][K][64]
+  std::vector<float> bias;  // [ptiles][16]
+  int ptiles = 0, J = 0;
+};
+template <typename WGet, typename BGet>
+inline PackedGate16 pack_gate16(int half, int Cin, int K, WGet wget, BGet bget, bool has_bias) {
+  PackedGate16 p;
+  p.ptiles = (half + 7) / 8;
+  p.J = (Cin + 31) / 32;
+  p.w.assign((size_t)p.ptiles * 8 * p.J * K * 64, 0.f);
+  p.bias.assign((size_t)p.ptiles * 16, 0.f);
+  for (int t = 0; t < p.ptiles; ++t) {
+    for (int m = 0; m < 16; ++m) {
+      const int c = 8 * t + (m & 7);
+      if (c >= half) continue;
+      const int co = (m >> 3) * half + c;
+      if (has_bias) p.bias[(size_t)t * 16 + m] = bget(co);
+      for (int g = 0; g < 8; ++g)
+        for (int j = 0; j < p.J; ++j)
+          for (int kq = 0; kq < 4; ++kq) {
+            const int ci = 4 * (g + 8 * j) + kq;
+            if (ci >= Cin) continue;
+            for (int k = 0; k < K; ++k)
+              p.w[((((size_t)t * 8 + g) * p.J + j) * K + k) * 64 + 16 * kq + m] = wget(co, ci, k);
+          }
+    }
+  }
+  return p;
+}
+
 }  // namespace mi355tts

@@ -242,7 +242,10 @@ def test_standard_utterance_properties(gpu_engine):
     assert int(mel.frames[0]) == F
     wav, i16 = gpu_engine.hifigan_infer(v, mel)
     assert wav.shape[1] == F * 256 and np.all(np.abs(wav) < 1.0) and np.isfinite(wav).all()
-    assert np.abs(i16).max() == 32767 or np.abs(wav).max() < 0.01
+    # peak-normalised: the peak sample is peak * fl(32767 / peak), which float32 rounding leaves at 32767 or a hair
+    # under it (truncated: 32766) — exactly what the reference's astype does, so pin it to the oracle on the same wav
+    assert np.abs(i16).max() >= 32766 or np.abs(wav).max() < 0.01
+    assert np.abs(i16[0].astype(np.int32) - audio_np.audio_float_to_int16(wav[0]).astype(np.int32)).max() <= 1
     mel2 = gpu_engine.glow_infer(g, ids, 0.667, 1.0, noise=noise, audio_settings=s)
     wav2, _ = gpu_engine.hifigan_infer(v, mel2)
     assert np.array_equal(wav, wav2)

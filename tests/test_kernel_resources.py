@@ -105,6 +105,23 @@ def test_narrow_stage_kernel_fits_three_workgroups_per_cu(resources):
         assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["lds"] <= 27 * 1024, (n, r)
 
 
+def test_glow_small_launch_kernels(resources):
+    """gate16 (two workgroups of 8 waves per CU at H = 192: <= 128 VGPRs, 36 KB of LDS) and the 8-wave attention (its
+    time IS its instruction count: no spills; one workgroup per CU by its 141 KB of LDS = two waves per SIMD = 256
+    registers a wave, and the shipped voices' dk = 96 variant well under that)."""
+    gate = {n: r for n, r in resources.items() if "gate16_kernel" in n}
+    assert len(gate) == 12, sorted(gate)
+    for n, r in gate.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 128, (n, r)
+    h192 = [r for n, r in gate.items() if "ILi5ELi6E" in n]
+    assert len(h192) == 1 and h192[0]["lds"] <= 37 * 1024
+    att = {n: r for n, r in resources.items() if "attention_mfma_kernel" in n}
+    assert len(att) == 8, sorted(att)
+    for n, r in att.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 256, (n, r)
+    assert [r["vgprs"] for n, r in att.items() if "ILi48ELb1E" in n][0] <= 128
+
+
 def test_two_workgroups_per_cu_where_the_schedule_counts_on_it(resources):
     conv = conv_variants(resources)
     assert conv
