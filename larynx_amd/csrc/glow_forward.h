@@ -14,6 +14,55 @@ static int run_layernorm(Worker* w, const float* x, const float* res, const floa
   return 0;
 }
 
+// ---- column-owner launches (coltile.h).  Each returns 1 when the shape is not one the kernel takes (the caller then runs
+// the separate launches), 0 when launched.
+static bool glow_fuse_on(mi355tts_ctx* ctx) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GLOW_FUSE"); return e && std::atoi(e) != 0; }();
+  return !off && ctx->glow_fuse.load();
+}
+static int run_oproj_ln(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const GlowLayer& L, const float* att, float* x, int H,
+                        long long bs, int ld, const int* d_len, int host_len, int B, int Pmax) {
+  if (!glow_fuse_on(ctx) || !L.o16.ok || H > COL_MAXROWS || ld % 4 || Pmax <= 0) return 1;
+  const float* A = gm->arena;
+  OprojLnArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = att; a.res = x; a.y = x; a.bs = bs; a.ld = ld;
+  if (B == 1 && host_len >= 0) { a.len = nullptr; a.len_const = host_len; } else { a.len = d_len; }
+  a.len_mul = 1;
+  a.w = A + L.o16.w_off; a.b = A + L.o16.b_off; a.gamma = A + L.g1; a.beta = A + L.b1;
+  a.H = H; a.eps = 1e-4f;
+  ProfScope ps(ctx, w, KC_GLOW_ENC_CONV, 2.0 * (double)H * H * (double)Pmax * B);
+  hipLaunchKernelGGL(oproj_ln_kernel, dim3((Pmax + COL_T - 1) / COL_T, B), dim3(512), 0, w->stream, a);
+  return 0;
+}
+// the tail of block `Bk` and the start of `next` (nullptr after the last block in reverse order)
+static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const GlowBlock& Bk, const GlowBlock* next, const float* acts,
+                         const float* skip, float* hbuf, long long bsD, float* z, long long bsZ, int F2, const int* d_f2, int host_len,
+                         int B, int F2max) {
+  const mi355tts_glow_hparams& h = gm->hp;
+  const int H = h.hidden_channels, half = h.mel_channels * h.n_sqz / 2;
+  if (!glow_fuse_on(ctx) || !Bk.t_rs.ok || !Bk.t_end.ok || !Bk.t_st.ok || (next && !next->t_st.ok) || h.n_split != 4 || (half % 2) || F2 % 4 ||
+      F2max <= 0)
+    return 1;
+  const float* A = gm->arena;
+  GlowTailArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.acts = acts; a.skip = h.n_block_layers > 1 ? skip : nullptr; a.hnext = next ? hbuf : nullptr; a.h_bs = bsD; a.h_ld = F2;
+  a.z = z; a.z_bs = bsZ; a.z_ld = F2;
+  if (B == 1 && host_len >= 0) { a.len = nullptr; a.len_const = host_len; } else { a.len = d_f2; }
+  a.len_mul = 1;
+  a.w_rs = A + Bk.t_rs.w_off; a.b_rs = A + Bk.t_rs.b_off;
+  a.w_end = A + Bk.t_end.w_off; a.b_end = A + Bk.t_end.b_off;
+  const GlowBlock& stb = next ? *next : Bk;  // the last block has no successor: its own start stands in (loaded, never used)
+  a.w_st = A + stb.t_st.w_off; a.b_st = A + stb.t_st.b_off;
+  a.mix_w = A + Bk.winv; a.mix_bias = A + Bk.an_bias; a.mix_scale = A + Bk.an_scale;
+  a.H = H; a.half = half;
+  const double mac = (double)H * H + 2.0 * half * H + (next ? (double)H * half : 0.0);
+  ProfScope ps(ctx, w, KC_GLOW_DEC_CONV, 2.0 * mac * (double)F2max * B);
+  hipLaunchKernelGGL(glow_tail_kernel, dim3((F2max + COL_T - 1) / COL_T, B), dim3(512), 0, w->stream, a);
+  return 0;
+}
+
 struct GlowCall {
   const int64_t* ids = nullptr;
   const int32_t* id_lens = nullptr;
@@ -211,7 +260,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
         hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
                            h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
     }
-    {
+    if (run_oproj_ln(ctx, w, gm, L, t2, x, H, bsH, P, d_len, enc_host_len, B, Pmax)) {
       ConvArgs a = base_args(t2, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, 0);
       a.res = x;
       CHECK(launch_conv(ctx, w, L.o, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
@@ -245,12 +294,18 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
     CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
-    {
+    if (glow_fuse_on(ctx) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
       ProfScope ps(ctx, w, KC_SMALL, 0);
-      run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
+      hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d1, (const float*)nullptr,
+                         A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, 0, 0, 1e-4f, A + gm->dpp_w, A + gm->dpp_b, logw, (long long)P);
+    } else {
+      {
+        ProfScope ps(ctx, w, KC_SMALL, 0);
+        run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
+      }
+      ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
+      CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     }
-    ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
   }
 
   // ---- durations -> frame counts (the one host sync of the path)
@@ -362,13 +417,15 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     for (int b = 0; b < B; ++b) w->pinned[b] = mel->frames[b] / nsq;
     HIPCHECK(hipMemcpyAsync(d_f2, w->pinned, sizeof(int) * B, hipMemcpyHostToDevice, s));
   }
+  bool start_done = false;  // the previous block's tail launch already ran this block's start conv
   for (int blk = h.n_blocks_dec - 1; blk >= 0; --blk) {  // models.py:195-206, reversed flows
     const GlowBlock& Bk = gm->blocks[blk];
-    {  // CouplingBlock reverse (attentions.py:119-142): h = start(x0)
+    if (!start_done) {  // CouplingBlock reverse (attentions.py:119-142): h = start(x0)
       ConvArgs a = base_args(z, bsZ, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       CHECK(launch_conv(ctx, w, Bk.start, a, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
     }
     int dil = 1;
+    bool tail_done = false;
     for (int j = 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
@@ -380,6 +437,12 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       const int g16 = run_gate16(ctx, w, Bk.in[j], a, B, F2max, KC_GLOW_DEC_CONV, s);
       if (g16 < 0) return g16;
       if (g16 == 1) CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
+      if (j == h.n_block_layers - 1) {
+        // last layer: res_skip (all skip) + end + coupling + InvConvNear/ActNorm + the next block's start in ONE launch
+        const GlowBlock* next = blk > 0 ? &gm->blocks[blk - 1] : nullptr;
+        tail_done = run_glow_tail(ctx, w, gm, Bk, next, acts, skip, hbuf, bsD, z, bsZ, F2, d_f2, dec_host_len, B, F2max) == 0;
+        if (tail_done) break;
+      }
       ConvArgs r = base_args(acts, bsD, F2, d_f2, 1, hbuf, bsD, F2, d_f2, 1, 1, 0);
       if (j < h.n_block_layers - 1) {
         r.res = hbuf;  // x = x + res_skip[:H]
@@ -394,6 +457,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       dil *= h.dilation_rate;
     }
+    start_done = tail_done;
+    if (tail_done) continue;
     {  // m, logs = end(wn_out);  z1 = (x1 - m) * exp(-logs)
       ConvArgs a = base_args(skip, bsD, F2, d_f2, 1, z + (size_t)half * F2, bsZ, F2, d_f2, 1, 1, 0);
       a.res = z + (size_t)half * F2;

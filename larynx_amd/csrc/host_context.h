@@ -50,6 +50,7 @@ struct mi355tts_ctx {
   std::atomic<int> active_calls{0};
   std::atomic<bool> adaptive_schedule{false};
   std::atomic<bool> gate16{true};     // GlowTTS WaveNet gate convs on 16-row tiles (gate16.h) when the launch is small
+  std::atomic<bool> glow_fuse{true};  // GlowTTS column-owner launches (coltile.h): block tails, conv_o + LayerNorm
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise

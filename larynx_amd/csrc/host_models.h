@@ -43,6 +43,12 @@ struct DevConv {
   int g16_J = 0;  // 4-channel groups per k-group; 0 = no such packing
 };
 
+// a dense 1 x 1 conv packed for the column-owner launches (pack_col16); w_off == 0 and ok == false when absent
+struct DevCol {
+  size_t w_off = 0, b_off = 0;
+  bool ok = false;
+};
+
 struct ArenaBuilder {
   std::vector<float> host;
   size_t add(const float* p, size_t n) {
@@ -130,6 +136,18 @@ static void add_gate16(ArenaBuilder& ab, DevConv& d, const float* w, const float
   d.g16_b_off = ab.add(p.bias);
 }
 
+// the column-owner packing of a 1 x 1 conv w[rows][K] (coltile.h takes up to COL_MAXROWS rows / K-depth)
+static DevCol add_col16(ArenaBuilder& ab, const float* w, const float* bias, int rows, int K) {
+  DevCol d;
+  if (rows > COL_MAXROWS || K > COL_MAXROWS) return d;
+  PackedCol16 p = pack_col16(
+      rows, K, [&](int r, int k) { return w[(size_t)r * K + k]; }, [&](int r) { return bias[r]; }, bias != nullptr);
+  d.w_off = ab.add(p.w);
+  d.b_off = ab.add(p.bias);
+  d.ok = true;
+  return d;
+}
+
 struct Blob {
   const float* p;
   int64_t n;
@@ -151,11 +169,14 @@ struct Blob {
 struct GlowLayer {
   DevConv qkv, o, ffn1, ffn2;
   size_t ek, ev, g1, b1, g2, b2;
+  DevCol o16;  // conv_o once more, packed for oproj_ln_kernel (coltile.h)
 };
 struct GlowBlock {
   DevConv start, end;
   std::vector<DevConv> in, rs;
   size_t winv, an_bias, an_scale;
+  // the column-owner packings of glow_tail_kernel (coltile.h): res_skip_layers[last], end (rows in natural order), start
+  DevCol t_rs, t_end, t_st;
 };
 // Models are handed out as shared_ptr pins: a call keeps its models alive for its whole duration, mi355tts_unload only
 // drops the context's reference, and the device memory goes when the last call that uses the model has returned.
@@ -176,6 +197,7 @@ struct GlowModel {
   DevConv pre_proj;
   std::vector<GlowLayer> layers;
   DevConv proj_m, dp1, dp2, dpp;
+  size_t dpp_w = 0, dpp_b = 0;  // proj's plain weight row [Fd] and bias, for the LayerNorm kernel's fused projection
   size_t dg1, db1, dg2, db2;
   std::vector<GlowBlock> blocks;
 };

@@ -30,6 +30,7 @@
 #include "resblock_pair_bf16.h"
 #include "mrf_small.h"
 #include "gate16.h"
+#include "coltile.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -234,6 +235,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     std::memcpy(bqkv.data() + 2 * H, bv, sizeof(float) * H);
     L.qkv = add_conv(ab, wqkv.data(), bqkv.data(), 3 * H, H, 1, ROWS_PLAIN);
     L.o = add_conv(ab, wo, bo, H, H, 1, ROWS_PLAIN);
+    L.o16 = add_col16(ab, wo, bo, H, H);
     L.ek = ab.add(ek, (size_t)nrel * dk);
     L.ev = ab.add(ev, (size_t)nrel * dk);
     TAKE(g1, "encoder.encoder.norm_layers_1." + std::to_string(l) + ".gamma", H);
@@ -270,6 +272,8 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     gm->dp1 = add_conv(ab, w1, b1, Fd, H, k, ROWS_PLAIN);
     gm->dp2 = add_conv(ab, w2, b2, Fd, Fd, k, ROWS_PLAIN);
     gm->dpp = add_conv(ab, wp, bp, 1, Fd, 1, ROWS_PLAIN);
+    gm->dpp_w = ab.add(wp, Fd);
+    gm->dpp_b = ab.add(bp, 1);
     gm->dg1 = ab.add(g1, Fd);
     gm->db1 = ab.add(e1, Fd);
     gm->dg2 = ab.add(g2, Fd);
@@ -292,6 +296,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(ws, cp + ".start.weight", (int64_t)H * half);
     TAKE(bs, cp + ".start.bias", H);
     B.start = add_conv(ab, ws, bs, H, half, 1, ROWS_PLAIN);
+    B.t_st = add_col16(ab, ws, bs, H, half);
     for (int j = 0; j < h.n_block_layers; ++j) {
       std::string il = cp + ".wn.in_layers." + std::to_string(j);
       std::string rl = cp + ".wn.res_skip_layers." + std::to_string(j);
@@ -303,10 +308,12 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
       B.in.push_back(add_conv(ab, wi, bi, 2 * H, H, h.kernel_size_dec, ROWS_PAIR, H));
       add_gate16(ab, B.in.back(), wi, bi, H, H, h.kernel_size_dec);
       B.rs.push_back(add_conv(ab, wr, br, rsn, H, 1, ROWS_PLAIN));
+      if (j == h.n_block_layers - 1) B.t_rs = add_col16(ab, wr, br, H, H);
     }
     TAKE(we, cp + ".end.weight", (int64_t)C * H);
     TAKE(be, cp + ".end.bias", C);
     B.end = add_conv(ab, we, be, C, H, 1, ROWS_PAIR, half);
+    B.t_end = add_col16(ab, we, be, C, H);
     gm->blocks.push_back(std::move(B));
   }
 #undef TAKE
@@ -1088,6 +1095,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "gate16") == 0) {
     ctx->gate16 = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "glow_fuse") == 0) {
+    ctx->glow_fuse = value != 0;
     return 0;
   }
   if (std::strcmp(name, "mrf_group") == 0) {

@@ -93,9 +93,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 // Fast path for C <= 256: 16 columns x 16 channel groups per workgroup, the
 // column's values live in registers (one global read, one write), group sums
 // meet in LDS.
+// `proj_w` != nullptr: the normalised column is not stored but contracted with proj_w[C] (+ proj_b[0]) into
+// proj_y[b][t] — the duration predictor's norm_2 -> proj (1 x 1, C -> 1; glow_tts/models.py:39-49) in one launch.
 __global__ __launch_bounds__(256) void layernorm16_kernel(const float* x, const float* res, const float* gamma,
                                                           const float* beta, float* y, int C, long long bs, int ld,
-                                                          const int* len, int pre_relu, int post_relu, float eps) {
+                                                          const int* len, int pre_relu, int post_relu, float eps,
+                                                          const float* proj_w = nullptr, const float* proj_b = nullptr,
+                                                          float* proj_y = nullptr, long long proj_bs = 0) {
   __shared__ float red[16][17];
   const int b = blockIdx.y;
   const int tl = threadIdx.x & 15;
@@ -139,6 +143,28 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* x, const 
   for (int k = 0; k < 16; ++k) var += red[k][tl];
   var /= (float)C;
   const float rstd = rsqrtf(var + eps);
+  if (proj_w) {  // kernel-uniform
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = g + 16 * i;
+      if (c < C) {
+        float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (post_relu) o = fmaxf(o, 0.f);
+        d += o * proj_w[c];
+      }
+    }
+    __syncthreads();
+    red[g][tl] = d;
+    __syncthreads();
+    if (g == 0 && valid) {
+      float o = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) o += red[k][tl];
+      proj_y[(long long)b * proj_bs + t] = o + proj_b[0];
+    }
+    return;
+  }
   if (!valid) return;
   float* yb = y + (long long)b * bs + t;
 #pragma unroll

@@ -168,4 +168,32 @@ inline PackedGate16 pack_gate16(int half, int Cin, int K, WGet wget, BGet bget, 
   return p;
 }
 
+// A fragments for the column-owner launches (coltile.h): a dense W[rows][K] on 16-row tiles of v_mfma_f32_16x16x4_f32,
+// [row tile][group of 4 k-steps][64 lanes][4]: element j of lane (m = l & 15, kq = l >> 4) is W[16 rt + m][16 q + 4 j + kq].
+// Rows and K zero-padded to multiples of 16; the bias to whole row tiles.
+struct PackedCol16 {
+  std::vector<float> w, bias;
+  int RT = 0, KQ4 = 0;
+};
+template <typename WGet, typename BGet>
+inline PackedCol16 pack_col16(int rows, int K, WGet wget, BGet bget, bool has_bias) {
+  PackedCol16 p;
+  p.RT = (rows + 15) / 16;
+  p.KQ4 = (K + 15) / 16;
+  p.w.assign((size_t)p.RT * p.KQ4 * 256, 0.f);
+  p.bias.assign((size_t)p.RT * 16, 0.f);
+  for (int rt = 0; rt < p.RT; ++rt)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = rt * 16 + (lane & 15);
+      if (row >= rows) continue;
+      if (has_bias && lane < 16) p.bias[row] = bget(row);
+      for (int q = 0; q < p.KQ4; ++q)
+        for (int j = 0; j < 4; ++j) {
+          const int k = 16 * q + 4 * j + (lane >> 4);
+          if (k < K) p.w[(((size_t)rt * p.KQ4 + q) * 64 + lane) * 4 + j] = wget(row, k);
+        }
+    }
+  return p;
+}
+
 }  // namespace mi355tts

@@ -1,0 +1,87 @@
+"""The column-owner launches of the GlowTTS path (csrc/coltile.h) on the CPU emulator build, against the numpy oracle and
+against the separate launches they replace (option `glow_fuse` off):
+
+* `glow_tail_kernel` — res_skip[last] + end + coupling + InvConvNear/ActNorm reverse + the next block's start
+  (glow_tts/attentions.py:119-142, layers.py:138-162, :192-194, :238-272);
+* `oproj_ln_kernel`  — conv_o + residual + LayerNorm of an encoder layer (attentions.py:62-68).
+"""
+import numpy as np
+import pytest
+
+from larynx_amd import hparams as HP
+from larynx_amd import synthetic
+from oracle import glow_tts_np
+
+
+def _run(engine, hp, seed, lens, batch=False):
+    sd = synthetic.make_glow_state_dict(hp, seed=seed)
+    g = engine.load_glow(hp, sd)
+    rng = np.random.default_rng(seed + 1)
+    ids = [synthetic.synthetic_phoneme_ids(rng, n, hp.num_symbols) for n in lens]
+    out = []
+    try:
+        if batch:
+            mel = engine.glow_infer(g, ids, 0.0, 1.0)
+            raw = mel.numpy("raw")
+            for b in range(len(lens)):
+                out.append(raw[b][:, : mel.frames[b]])
+        else:
+            for i in ids:
+                mel = engine.glow_infer(g, i, 0.0, 1.0)
+                out.append(mel.numpy("raw")[0][:, : mel.frames[0]])
+        refs = [glow_tts_np.glow_tts_infer(sd, hp, i, None, 0.0, 1.0) for i in ids]
+    finally:
+        engine.unload(g)
+    return refs, out
+
+
+def _both(engine, hp, seed, lens, batch=False):
+    refs, on = _run(engine, hp, seed, lens, batch)
+    engine.set_option("glow_fuse", 0)
+    try:
+        _, off = _run(engine, hp, seed, lens, batch)
+    finally:
+        engine.set_option("glow_fuse", 1)
+    return refs, on, off
+
+
+@pytest.mark.parametrize(
+    "hidden,mel,layers",
+    [
+        (32, 8, 2),    # two row tiles, K = 32; half = 8: the start conv's K padded from 8 to 16
+        (96, 8, 1),    # one WaveNet layer: no earlier skip sum
+        (192, 80, 4),  # the released voices' shape: twelve row tiles (waves 0-3 own two), end = 160 rows, start K = 80
+        (160, 12, 2),  # ten row tiles: waves 0-1 own two, waves 2-7 one; half = 12 (K padded 12 -> 16, six channel groups)
+    ],
+)
+def test_block_tail_and_oproj_ln_match_the_oracle_and_the_separate_launches(emu_engine, hidden, mel, layers):
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=hidden, filter_channels=32, filter_channels_dp=32, n_blocks_dec=3,
+                        n_layers_enc=2, n_block_layers=layers, mel_channels=mel)
+    refs, on, off = _both(emu_engine, hp, 61, (9, 23))  # decoder lengths on both sides of a 16-column tile seam
+    for ref, a, b in zip(refs, on, off):
+        assert a.shape == ref.shape == b.shape
+        np.testing.assert_allclose(a, ref, atol=5e-5, rtol=1e-4)
+        np.testing.assert_allclose(b, ref, atol=5e-5, rtol=1e-4)
+        assert np.abs(a - b).max() < 2e-5  # the same arithmetic up to summation order
+
+
+def test_ragged_batch_rows_equal_single_calls(emu_engine):
+    """A padded batch of three rows: every row owns only its own column tiles, and a row's result does not depend on
+    its neighbours (bit-equal to the batch-1 call: the same kernels on the same columns)."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=64, filter_channels=32, filter_channels_dp=32, n_blocks_dec=2,
+                        n_layers_enc=2, n_block_layers=2, mel_channels=8)
+    lens = (37, 5, 18)
+    refs, batch = _run(emu_engine, hp, 67, lens, batch=True)
+    _, single = _run(emu_engine, hp, 67, lens, batch=False)
+    for ref, a, b in zip(refs, batch, single):
+        np.testing.assert_allclose(a, ref, atol=5e-5, rtol=1e-4)
+        assert np.array_equal(a, b)
+
+
+def test_shapes_outside_the_kernels_fall_back(emu_engine):
+    """n_split = 8 has no fused InvConvNear: the block tails run as separate launches, conv_o + LayerNorm still fuses."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=64, filter_channels=32, filter_channels_dp=32, n_blocks_dec=2,
+                        n_layers_enc=1, n_block_layers=2, mel_channels=8, n_split=8)
+    refs, on, off = _both(emu_engine, hp, 71, (21,))
+    np.testing.assert_allclose(on[0], refs[0], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(off[0], refs[0], atol=5e-5, rtol=1e-4)

@@ -1,0 +1,16 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03; mkdir -p $O
+bash tools/gpu/coltile_probe.sh
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|skipped|assert" | head -8
+B="python bench.py --no-cpu-baseline --no-config3 --no-config5"
+run() {  # label, env
+  env $2 timeout 300 $B 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); h=d.get('half_mode',{}); p=d['profile_ms_per_step']
+print('$1', 'utt/s', round(d['value'],1), 'lat', round(d['latency_ms_single_stream'],3), 'frac', round(d['roofline']['frac'],4), 'glow_dec', round(p.get('conv_mfma.glow_decoder',0),3), 'glow_enc', round(p.get('conv_mfma.glow_encoder',0),3), 'elementwise', round(p.get('elementwise',0),3), 'half', round(h.get('utterances_per_sec',0),1), round(h.get('latency_ms_single_stream',0),3), 'c4', round(d['config4']['utterances_per_sec']), round(d['config4']['ms_per_call'],3))"
+}
+for i in 1 2; do
+  run base MI355TTS_NO_GLOW_FUSE=1
+  run fused X=1
+  run fused_devkernarg HIP_FORCE_DEV_KERNARG=1
+done | tee $O/ab_glow_fuse.log
