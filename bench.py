@@ -481,6 +481,9 @@ def main():
     # hipMalloc / hipFree / stream creation can happen inside a timed region
     dn_ok = 88 * hop > 1024  # the denoiser's 1024-point STFT needs a real vocoder hop (not the emulator's tiny one)
     eng.reserve(conc + 1, g, v, max_batch=B, max_ids=max(args.ids, 200), max_frames=max(max_frames, 2400), denoiser=dn_ok)
+    if B == 1 and conc > 1:
+        # concurrent batch-1 calls share GlowTTS passes (csrc/host_join.h): any worker may lead a pass of up to `conc` rows
+        eng.reserve(conc + 1, g, 0, max_batch=conc, max_ids=max(args.ids, 200), max_frames=max_frames)
 
     def step(i, slot=0, denoiser=0.0):
         """One utterance (one batch of B) through the fused call; returns its frame count."""
@@ -560,6 +563,18 @@ def main():
     repeats = args.repeats if args.repeats > 0 else int(min(40, max(5, np.ceil(2.0 / est))))
     t_single = timed(lambda: run_steps(W, n_utts, threads=1), repeats)
     t_flight = timed(lambda: run_steps(W, n_utts), repeats) if conc > 1 else t_single
+    # the same region with the callers sharing GlowTTS passes (option glow_coalesce = 1, off by default), reported next to
+    # the headline
+    t_flight_nc = t_flight
+    cs0 = cs1 = (0, 0)
+    if conc > 1 and B == 1:
+        eng.set_option("glow_coalesce", 1)
+        run_steps(0, max(W, conc))
+        cs0 = eng.coalesce_stats()
+        t_flight_nc = timed(lambda: run_steps(W, n_utts), max(3, repeats // 3))
+        cs1 = eng.coalesce_stats()
+        eng.set_option("glow_coalesce", 0)
+        run_steps(0, max(W, conc))
     t_dn = timed(lambda: run_steps(W, n_utts, denoiser=0.005), max(3, repeats // 3)) if dn_ok else [float("nan")]
 
     def med(x):
@@ -587,7 +602,7 @@ def main():
         half = (med(h_flight), med(h_single), hprof["conv_mfma.hifigan_resblock"])
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
-                          half[0] if half else 0.0, half[1] if half else 0.0], dtype=torch.float64, device=red_dev)
+                          half[0] if half else 0.0, half[1] if half else 0.0, med(t_flight_nc)], dtype=torch.float64, device=red_dev)
     per_rank = [[float(stats[0]), float(stats[1])]]  # this rank's (in-flight, single-stream) seconds per K-step region
     if use_dist:
         gathered = [None] * world
@@ -601,7 +616,7 @@ def main():
         stats = mx
     else:
         total_frames = float(frames)
-    dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single = (float(x) for x in stats)
+    dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single, dt_flight_nc = (float(x) for x in stats)
 
     # ---- BASELINE config 3: 256 utterances, LPT-sharded over the ranks, ordered gather (strong scaling)
     c3 = None
@@ -637,6 +652,8 @@ def main():
             return out
 
         eng.reserve(conc + 1, g, v, max_batch=1, max_ids=max(lengths), max_frames=max(lengths) * 12)
+        if conc > 1:
+            eng.reserve(conc + 1, g, 0, max_batch=conc, max_ids=max(lengths), max_frames=max(lengths) * 12)
         shard_job()  # warm (host staging buffers at the largest shape)
         barrier()
         t0 = time.perf_counter()
@@ -785,6 +802,15 @@ def main():
             "rtf_single_stream": dt_single * world / audio_s,
             "x_realtime_single_stream": audio_s / (dt_single * world),
             "end_to_end_tflops_per_gpu": flop_utt * K * B / dt_flight / 1e12,
+            "glow_coalescing": None if not (conc > 1 and B == 1) else {
+                "what": "option glow_coalesce = 1 (default 0): concurrent batch-1 calls share GlowTTS passes — the callers waiting when a "
+                        "pass starts become the rows of one padded batch (csrc/host_join.h); bit-identical results "
+                        "(tests/test_emu_coalesce.py, tests/test_gpu_parity.py::test_coalesced_calls_equal_their_solitary_results). "
+                        "NOT the headline: the same timed region with the option on",
+                "rows_per_pass": (cs1[1] - cs0[1]) / max(1, cs1[0] - cs0[0]),
+                "utterances_per_sec": world * K * B / dt_flight_nc,
+                "ms_per_step": 1e3 * dt_flight_nc / K,
+            },
             "denoiser_on": None if not dn_ok else {
                 "denoiser_strength": 0.005,
                 "note": "the reference CLI/server default (larynx/__main__.py:512-516); STFT denoiser on the device",

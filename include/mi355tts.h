@@ -235,9 +235,18 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * three (used when timing single kernels); "mrf_group" (0/1, default 1) — the
  * same-geometry launches of the three chains go out as one grouped launch; "adaptive_schedule"
  * (0/1, default 0) — while other calls are in flight, launch the members of a group one by one
- * (and, with "mrf_group" = 0, do not fork the chains onto side streams).  Results are the same bits
- * under every setting. */
+ * (and, with "mrf_group" = 0, do not fork the chains onto side streams); "gate16", "glow_fuse", "mrf_small" (0/1, default 1)
+ * — the small-launch kernels of gate16.h / coltile.h / mrf_small.h (0 = the generic tiles; same results up to summation
+ * order); "glow_coalesce" (below).  The schedule options give the same bits under every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
+/* Option "glow_coalesce" (0/1, default 0): concurrent batch-1 mi355tts_synthesize calls (the reference's per-sentence
+ * thread pool, larynx/__init__.py:146-157, 187-190) share GlowTTS passes — the callers waiting when a pass starts become
+ * the rows of ONE padded batch; each row keeps the noise stream of its own seed and is computed by the launches of its own
+ * batch-1 call, so results are the same bits with the option on or off, whoever shared the pass.  Off by default: with the
+ * 'high' vocoder the shared passes buy nothing (the waiting they introduce costs what the saved launches gain; measured in
+ * profiles/NOTES.md) — for loads where GlowTTS dominates.  Counters since the context was created: passes run with the
+ * option on, rows they carried. */
+int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
 

@@ -72,6 +72,12 @@ struct GlowCall {
   int noise_ld = 0;
   uint64_t seed = 0;
   const uint64_t* row_seeds = nullptr;  // optional, host, [B]: the noise stream of row b (default seed + b)
+  // optional, host, [B]: row b's ids live at row_ids[b] (id_lens[b] of them; host or device per `flags`) instead of
+  // ids + b * ids_ld — the rows of a coalesced pass come from different callers (host_join.h)
+  const int64_t* const* row_ids = nullptr;
+  // every launch on the smallest tile whatever the batch size: what a batch-1 call uses up to ~5000 decoder columns, so
+  // a row of a coalesced pass is computed by exactly the launches (and summation orders) of its own batch-1 call
+  bool solo_tiles = false;
   const mi355tts_audio_settings* audio = nullptr;
   uint32_t flags = 0;
 };
@@ -86,7 +92,7 @@ static int find_glow(mi355tts_ctx* ctx, int glow, std::shared_ptr<GlowModel>* ou
 }
 
 static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) {
-  if (!c.ids || !c.id_lens) return fail(MI355TTS_ERR_INVALID, "null argument");
+  if ((!c.ids && !c.row_ids) || !c.id_lens) return fail(MI355TTS_ERR_INVALID, "null argument");
   if (c.B <= 0 || c.ids_ld <= 0) return fail(MI355TTS_ERR_INVALID, "empty batch");
   int Pmax = 0;
   for (int b = 0; b < c.B; ++b) {
@@ -99,7 +105,7 @@ static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) 
     // device-resident ids cannot be checked without a sync and are clamped by the kernel instead
     for (int b = 0; b < c.B; ++b)
       for (int t = 0; t < c.id_lens[b]; ++t) {
-        const int64_t id = c.ids[(size_t)b * c.ids_ld + t];
+        const int64_t id = c.row_ids ? c.row_ids[b][t] : c.ids[(size_t)b * c.ids_ld + t];
         if (id < 0 || id >= gm->hp.num_symbols)
           return fail(MI355TTS_ERR_INVALID, "phoneme id %lld at [%d][%d] outside [0,%d)", (long long)id, b, t, gm->hp.num_symbols);
       }
@@ -177,7 +183,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   const int enc_host_len = B == 1 ? id_lens[0] : -1;
   // workgroup target per GlowTTS conv launch (tile-shape choice; tuning knob MI355TTS_GLOW_TILES)
   static const int glow_tiles_env = [] { const char* e = std::getenv("MI355TTS_GLOW_TILES"); return e ? std::atoi(e) : 0; }();
-  const int glow_tiles = glow_tiles_env > 0 ? glow_tiles_env : 1024;
+  const int glow_tiles = call.solo_tiles ? (1 << 30) : glow_tiles_env > 0 ? glow_tiles_env : 1024;
   {
     long long sum = 0;
     for (int b = 0; b < B; ++b) sum += id_lens[b];
@@ -210,7 +216,14 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     d_seeds = (unsigned long long*)(base + el.o_seed);
     HIPCHECK(hipMemcpyAsync(d_seeds, call.row_seeds, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, s));
   }
-  HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  if (call.row_ids) {
+    HIPCHECK(hipMemsetAsync(d_ids, 0, sizeof(long long) * (size_t)B * ids_ld, s));
+    for (int b = 0; b < B; ++b)
+      HIPCHECK(hipMemcpyAsync(d_ids + (size_t)b * ids_ld, call.row_ids[b], sizeof(long long) * (size_t)id_lens[b],
+                              in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else {
+    HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  }
 
   const long long bsH = (long long)H * P;
   {

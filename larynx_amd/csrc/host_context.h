@@ -53,6 +53,14 @@ struct mi355tts_ctx {
   std::atomic<bool> glow_fuse{true};  // GlowTTS column-owner launches (coltile.h): block tails, conv_o + LayerNorm
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
+  // concurrent batch-1 mi355tts_synthesize calls share ONE GlowTTS pass (host_join.h): the callers waiting when a pass
+  // starts become its rows.  Off by default: measured neutral to -1 % on the 'high' vocoder (profiles/NOTES.md)
+  std::atomic<bool> glow_coalesce{false};
+  std::mutex join_mu;
+  std::condition_variable join_cv;
+  std::vector<struct GlowJoinReq*> join_q;
+  bool join_busy = false;
+  long long join_passes = 0, join_rows = 0;  // under join_mu
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -742,6 +743,7 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
 
 #include "glow_forward.h"
 #include "hifigan_forward.h"
+#include "host_join.h"
 
 // ------------------------------------------------------------------ fused call + reservation
 // ids -> int16/f32 waveform in ONE call on ONE worker: GlowTTS and the vocoder are queued
@@ -788,6 +790,34 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
   Worker* w = nullptr;
   CHECK(acquire_worker(ctx, &w));
   WorkerGuard guard{ctx, w};
+  static const bool no_coalesce = [] { const char* e = std::getenv("MI355TTS_NO_GLOW_COALESCE"); return e && std::atoi(e) != 0; }();
+  if (B == 1 && !noise && !no_coalesce && ctx->glow_coalesce.load() && id_lens[0] <= ATTM_MAXP) {
+    // a batch-1 call: its GlowTTS pass is shared with whichever other batch-1 calls are waiting right now (host_join.h)
+    GlowJoinReq req;
+    req.gm = gm;
+    req.ids = ids;
+    req.len = id_lens[0];
+    req.noise_scale = noise_scale;
+    req.length_scale = length_scale;
+    req.seed = seed;
+    req.audio = audio;
+    req.flags = g.flags;
+    CHECK(glow_join(ctx, w, req));
+    mi355tts_mel view;
+    glow_join_view(req, &view);
+    struct BatchDrop {
+      Worker* w;
+      std::shared_ptr<GlowBatch>* b;
+      ~BatchDrop() {
+        hipStreamSynchronize(w->stream);  // the row's blocks go back to the pool with the last caller: nothing of ours may still read them
+        b->reset();
+      }
+    } drop{w, &req.batch};
+    frames_out[0] = view.frames[0];
+    if (req.batch->ready) HIPCHECK(hipStreamWaitEvent(w->stream, req.batch->ready, 0));
+    CHECK(hifigan_precheck(ctx, hm, vocoder, view.frames.data(), 1, view.M, view.max_frames, v));
+    return hifigan_run(ctx, w, hm, &view, v);
+  }
   mi355tts_mel* mel = nullptr;
   CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
   struct MelDrop {
@@ -1097,6 +1127,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->gate16 = value != 0;
     return 0;
   }
+  if (std::strcmp(name, "glow_coalesce") == 0) {
+    ctx->glow_coalesce = value != 0;
+    return 0;
+  }
   if (std::strcmp(name, "glow_fuse") == 0) {
     ctx->glow_fuse = value != 0;
     return 0;
@@ -1110,6 +1144,13 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     return 0;
   }
   return fail(MI355TTS_ERR_INVALID, "unknown option '%s'", name);
+}
+extern "C" int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows) {
+  if (!ctx || !passes || !rows) return fail(MI355TTS_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->join_mu);
+  *passes = ctx->join_passes;
+  *rows = ctx->join_rows;
+  return 0;
 }
 extern "C" int mi355tts_profile_reset(mi355tts_ctx* ctx) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");

@@ -402,6 +402,12 @@ class Engine:
     def set_option(self, name: str, value: int):
         ffi.check(self.lib, self.lib.mi355tts_set_option(self._ctx, name.encode("ascii"), int(value)))
 
+    def coalesce_stats(self):
+        """(passes, rows) of the shared GlowTTS passes since the context was created (see include/mi355tts.h)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        ffi.check(self.lib, self.lib.mi355tts_coalesce_stats(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def profile_reset(self):
         ffi.check(self.lib, self.lib.mi355tts_profile_reset(self._ctx))
 

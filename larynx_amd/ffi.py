@@ -131,6 +131,7 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
     "mi355tts_bench_conv1d": (C.c_int, [_VP] + [C.c_int] * 8 + [C.POINTER(C.c_float)]),
     "mi355tts_set_profiling": (C.c_int, [_VP, C.c_int]),
     "mi355tts_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "mi355tts_coalesce_stats": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi355tts_profile_reset": (C.c_int, [_VP]),
     "mi355tts_profile_json": (C.c_int, [_VP, C.c_char_p, C.c_int]),
 }

@@ -280,6 +280,49 @@ def test_threads_share_one_engine(gpu_engine):
         assert np.array_equal(a, b)
 
 
+def test_coalesced_calls_equal_their_solitary_results(gpu_engine):
+    """csrc/host_join.h on the device: eight threads' batch-1 fused calls (ragged lengths on both sides of the 16- and
+    32-column tile seams, the device RNG on) share GlowTTS passes, and every caller gets the bits of its solitary call —
+    its own seed's noise stream, the launches of a batch-1 call — in f32 and in the split-bf16 mode."""
+    import threading
+
+    from larynx_amd import ffi
+
+    (gsd, g), (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    s = ljspeech_audio_settings()
+    rng = np.random.default_rng(77)
+    lens = (120, 33, 64, 97, 120, 15, 81, 50)
+    ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in lens]
+    for precision in (ffi.PRECISION_F32, ffi.PRECISION_BF16X3):
+        gpu_engine.set_precision(v, precision)
+        try:
+            gpu_engine.set_option("glow_coalesce", 0)
+            solo = [gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True) for i in range(len(ids))]
+            gpu_engine.set_option("glow_coalesce", 1)
+            p0, r0 = gpu_engine.coalesce_stats()
+            for rep in range(3):
+                out = [None] * len(ids)
+                bar = threading.Barrier(len(ids))
+
+                def work(i):
+                    bar.wait()
+                    out[i] = gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True)
+
+                th = [threading.Thread(target=work, args=(i,)) for i in range(len(ids))]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                for (fa, wa, ia), (fb, wb, ib) in zip(solo, out):
+                    assert np.array_equal(fa, fb)
+                    assert np.array_equal(wa, wb) and np.array_equal(ia, ib)
+            p1, r1 = gpu_engine.coalesce_stats()
+            assert r1 - r0 >= 3 * len(ids) and p1 - p0 < r1 - r0, (p1 - p0, r1 - r0)  # passes were shared
+        finally:
+            gpu_engine.set_option("glow_coalesce", 0)
+            gpu_engine.set_precision(v, ffi.PRECISION_F32)
+
+
 def test_long_utterance_and_three_resident_voices(gpu_engine):
     """BASELINE config 5 shape: three voices (en V=46, de V=54, fr V=42) resident at
     once, interleaved calls; plus a long (400-id) sentence at 'low' quality:

@@ -51,6 +51,28 @@ for r in range(2):
     voc = run(lambda i: eng.hifigan_infer(v, mels[i], want_float=False, want_int16=True))
     glow = run(lambda i: eng.glow_infer(g, ids, 0.667, 0.65, seed=i, audio_settings=s))
     full = run(lambda i: eng.synthesize(g, v, ids, 0.667, 0.65, seed=i, audio_settings=s, frames_per_id_guess=12.0 / 0.65))
+    # the same vocoder load with ONE extra thread running batched GlowTTS passes (B = nthr rows per call) back to back: what
+    # a pass costs the vocoder calls = the price of GlowTTS if concurrent callers' passes were coalesced
+    stop = threading.Event()
+    passes = [0]
+
+    def glow_bg():
+        rows = [ids] * nthr
+        while not stop.is_set():
+            eng.glow_infer(g, rows, 0.667, 0.65, seed=3, audio_settings=s).free()
+            passes[0] += 1
+
+    bg = threading.Thread(target=glow_bg)
+    bg.start()
+    t_bg = time.perf_counter()
+    voc_bg = run(lambda i: eng.hifigan_infer(v, mels[i], want_float=False, want_int16=True))
+    dt_bg = time.perf_counter() - t_bg
+    stop.set()
+    bg.join()
+    n_voc = nthr * (ncall + 3)
+    print(f"   vocoder with batched GlowTTS passes in the background: {voc_bg:.1f} /s ({1e3 / voc_bg:.3f} ms); {passes[0]} passes of {nthr} rows in "
+          f"{dt_bg * 1e3:.0f} ms = {passes[0] * nthr / n_voc:.2f} rows per vocoder call -> extra time per vocoder call "
+          f"{1e3 / voc_bg - 1e3 / voc:.3f} ms, per GlowTTS row {(1e3 / voc_bg - 1e3 / voc) * n_voc / max(passes[0] * nthr, 1):.3f} ms")
     print(f"{nthr} calls in flight: vocoder alone {voc:.1f} /s ({1e3 / voc:.3f} ms), GlowTTS alone {glow:.1f} /s ({1e3 / glow:.3f} ms), "
           f"full call {full:.1f} /s ({1e3 / full:.3f} ms); sum of the parts {1e3 / voc + 1e3 / glow:.3f} ms")
 eng.close()
