@@ -146,4 +146,135 @@ __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
   GATE_STAMP(4);
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lin16_kernel: the same tile for the PLAIN k-tap convs of the GlowTTS encoder whose K-depth is long and whose time axis is
+// short — FFN conv_1 / conv_2 (attentions.py:375-383: 192 -> 768 -> 192, k = 3), the duration predictor's convs
+// (models.py:39-49) and the prenet (layers.py:73-80, k = 5).  On the generic 32-row tile these are 24-96 workgroups that walk
+// their K-depth in staged chunks of 64 channels (conv_2: twelve chunks, each a global -> LDS round trip and a barrier):
+// 13 us per launch at P = 120, 17 us in a padded batch of 8.  Here the whole input tile is staged ONCE, every A fragment is
+// requested at entry, and 16-row tiles double the workgroup count.  Epilogue: y = act(acc + bias [+ res]).
+struct Lin16Args {
+  const float* x;  // [B][Cin][x_ld]
+  long long x_bs;
+  int x_ld;
+  const int* len;  // valid columns per batch row: len ? len[b] * len_mul : len_const (input and output)
+  int len_mul, len_const;
+  const float* w;     // pack_lin16: [row tile][k-group][J][K][64 lanes]
+  const float* bias;  // [row tile][16] (zeros when the conv has none)
+  int Cin, rows;
+  int dil, pad;
+  float* y;  // [B][rows][y_ld]
+  long long y_bs;
+  int y_ld;
+  const float* res;  // optional residual, geometry of y
+  int relu;
+};
+
+// K taps, J = 4-channel groups per k-group (Cin <= 32 J), NBLK = 16-column blocks per workgroup (1 or 2)
+template <int K, int J, int NBLK>
+__global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
+  constexpr int TC = 16 * NBLK;  // columns per workgroup
+  constexpr int XW = TC + 16;    // staged columns per channel row
+  __shared__ float xs[(32 * J * XW > 2048 * NBLK) ? 32 * J * XW : 2048 * NBLK];  // [32 J][XW]; afterwards the partial tiles [8][NBLK][4][64]
+  const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
+  const int b = blockIdx.z;
+  const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
+  const int gx = (L + TC - 1) / TC, gy = gridDim.y;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (lin >= gx * gy) return;  // ragged batch: a row deals only its own tiles
+  int tx, ty;
+  {
+    const int n = gx * gy, xcd = lin & 7, slot = lin >> 3, q = n >> 3, r = n & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tx = id % gx;
+    ty = id / gx;
+  }
+  const int t0 = tx * TC;
+  constexpr int CP = 32 * J;
+  constexpr int XW4 = XW / 4;
+  const int PA = (a.pad + 3) & ~3;
+
+  // ---- every load whose address is known at entry
+  float af[J][K];
+  {
+    const float* wp = a.w + ((long long)(ty * 8 + kg) * (J * K)) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int k = 0; k < K; ++k) af[j][k] = wp[(j * K + k) * 64];
+  }
+  constexpr int NF4 = CP * XW4, NE = (NF4 + 511) / 512;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  float4 pre[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 512 * i;
+    const int row = e / XW4, f = e - row * XW4;
+    const int c0 = t0 - PA + 4 * f;
+    const int ci = row < a.Cin ? row : a.Cin - 1;
+    pre[i] = *reinterpret_cast<const float4*>(xb + (long long)ci * a.x_ld + (c0 < 0 ? 0 : (c0 > a.x_ld - 4 ? a.x_ld - 4 : c0)));
+  }
+  // the epilogue's operands too: thread (row i, column n) of the tile
+  const int ei = tid / TC, en = tid - ei * TC;
+  const bool ethread = tid < 16 * TC;
+  const int erow = ty * 16 + (ethread ? ei : 0), et = t0 + en;
+  const bool eok = ethread && erow < a.rows && et < L;
+  const float ebias = a.bias[ty * 16 + (ethread ? ei : 0)];
+  float eres = 0.f;
+  if (a.res) eres = a.res[(long long)b * a.y_bs + (long long)(eok ? erow : 0) * a.y_ld + (eok ? et : 0)];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 512 * i;
+    const int row = e / XW4, f = e - row * XW4;
+    const int c0 = t0 - PA + 4 * f;
+    const bool rok = row < a.Cin;
+    float4 v = pre[i];
+    v.x = (rok && c0 >= 0 && c0 < L) ? v.x : 0.f;
+    v.y = (rok && c0 + 1 >= 0 && c0 + 1 < L) ? v.y : 0.f;
+    v.z = (rok && c0 + 2 >= 0 && c0 + 2 < L) ? v.z : 0.f;
+    v.w = (rok && c0 + 3 >= 0 && c0 + 3 < L) ? v.w : 0.f;
+    if (e < NF4) reinterpret_cast<float4*>(xs)[e] = v;
+  }
+  __syncthreads();
+
+  // ---- main loop: B fragment lane (n = lane & 15, kq = lane >> 4) = x[4 (g + 8 j) + kq][t0 + n + k dil - pad]
+  gate_floatx4 acc[NBLK];
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb) acc[nb] = gate_floatx4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* bp = xs + (4 * kg + (lane >> 4)) * XW + (lane & 15) + (PA - a.pad);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float* p = bp + (32 * j) * XW + k * a.dil;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[16 * nb], acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the k-groups' partial tiles: red[kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
+  {
+    float* red = xs + (kg * NBLK) * 256 + lane;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[nb * 256 + r * 64] = acc[nb][r];
+  }
+  __syncthreads();
+  if (ethread) {
+    const int src = (en >> 4) * 256 + (ei & 3) * 64 + (ei >> 2) * 16 + (en & 15);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += xs[g * (NBLK * 256) + src];
+    v += ebias;
+    v += eres;
+    if (a.relu) v = v > 0.f ? v : 0.f;
+    if (eok) a.y[(long long)b * a.y_bs + (long long)erow * a.y_ld + et] = v;
+  }
+}
+
 }  // namespace mi355tts

@@ -63,6 +63,13 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
   return 0;
 }
 
+// an encoder conv: the 16-row tile with the input staged once when the shape has one (lin16_kernel), else the generic tile
+static int launch_enc_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const DevConv& c, const ConvArgs& a, int B, int Pmax,
+                           int glow_tiles, int host_len) {
+  if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len) == 0) return 0;
+  return launch_conv(ctx, w, c, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, host_len);
+}
+
 struct GlowCall {
   const int64_t* ids = nullptr;
   const int32_t* id_lens = nullptr;
@@ -236,7 +243,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const float* cur = x;
     for (int i = 0; i < h.prenet_layers; ++i) {
       ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
-      CHECK(launch_conv(ctx, w, gm->pre_conv[i], a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, gm->pre_conv[i], a, B, Pmax, glow_tiles, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
       cur = t2;
@@ -283,10 +290,10 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     {  // FFN, attentions.py:375-383
       ConvArgs a = base_args(x, bsH, P, d_len, 1, ffn, (long long)Fc * P, P, d_len, 1, 1, k / 2);
       a.out_act = ACT_RELU;
-      CHECK(launch_conv(ctx, w, L.ffn1, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.ffn1, a, B, Pmax, glow_tiles, enc_host_len));
       ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
       c.res = x;
-      CHECK(launch_conv(ctx, w, L.ffn2, c, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.ffn2, c, B, Pmax, glow_tiles, enc_host_len));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
     }
@@ -299,14 +306,14 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp1, c1, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->dp1, c1, B, Pmax, glow_tiles, enc_host_len));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
-    CHECK(launch_conv(ctx, w, gm->dp2, c2, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->dp2, c2, B, Pmax, glow_tiles, enc_host_len));
     if (glow_fuse_on(ctx) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
       ProfScope ps(ctx, w, KC_SMALL, 0);
       hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d1, (const float*)nullptr,

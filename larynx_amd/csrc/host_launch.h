@@ -665,6 +665,40 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   return 0;
 }
 
+// ---- a plain encoder conv on 16-row tiles with the whole input tile staged once (lin16_kernel, gate16.h).  Returns 1 when
+// this conv / launch is not one the kernel takes (the caller then launches the generic tile), 0 when launched.
+static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvArgs& a, const float* arena, int B, int n_max, int cls,
+                     int host_len) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_LIN16"); return e && std::atoi(e) != 0; }();
+  // more tiles than this and the chunked 32-row tile fills the chip (longer rows, bigger batches)
+  static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_LIN16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
+  if (off || !ctx->glow_fuse.load() || !c.l16_J || n_max <= 0) return 1;
+  const int PA = (a.pad + 3) & ~3;
+  if ((PA - a.pad) + (c.K - 1) * a.dil > 16 || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
+  if (a.x2 || a.y2 || a.split < c.rows || a.alpha != 1.0f || a.accum || a.in_slope != 1.0f || (a.out_act != ACT_NONE && a.out_act != ACT_RELU))
+    return 1;
+  const int nblk = c.l16_J >= 16 ? 1 : 2;
+  const int TC = 16 * nblk;
+  const int gx = (n_max + TC - 1) / TC, gy = (c.rows + 15) / 16;
+  if ((long long)gx * gy * B > max_tiles) return 1;
+  Lin16Args g;
+  std::memset(&g, 0, sizeof(g));
+  g.x = a.x; g.x_bs = a.x_bs; g.x_ld = a.x_ld;
+  if (B == 1 && host_len >= 0) { g.len = nullptr; g.len_const = host_len * a.in_mul; } else { g.len = a.in_len; g.len_const = a.in_const; }
+  g.len_mul = a.in_mul;
+  g.w = arena + c.l16_w_off; g.bias = arena + c.l16_b_off; g.Cin = c.Cin; g.rows = c.rows; g.dil = a.dil; g.pad = a.pad;
+  g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld; g.res = a.res; g.relu = a.out_act == ACT_RELU;
+  ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B);
+  const dim3 grid(gx, gy, B);
+  hipStream_t s = w->stream;
+  if (c.K == 3 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 6, 2>), grid, dim3(512), 0, s, g);
+  else if (c.K == 3 && c.l16_J == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 8, 2>), grid, dim3(512), 0, s, g);
+  else if (c.K == 3 && c.l16_J == 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 24, 1>), grid, dim3(512), 0, s, g);
+  else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
+  else return 1;
+  return 0;
+}
+
 static ConvArgs base_args(const float* x, long long x_bs, int x_ld, const int* in_len, int in_mul, float* y, long long y_bs,
                           int y_ld, const int* out_len, int out_mul, int dil, int pad) {
   ConvArgs a;

@@ -41,6 +41,9 @@ struct DevConv {
   const float* g16_w = nullptr;
   const float* g16_b = nullptr;
   int g16_J = 0;  // 4-channel groups per k-group; 0 = no such packing
+  // the 16-row-tile packing of a plain encoder conv (lin16_kernel, gate16.h), present for the shapes the kernel is built for
+  size_t l16_w_off = 0, l16_b_off = 0;
+  int l16_J = 0;
 };
 
 // a dense 1 x 1 conv packed for the column-owner launches (pack_col16); w_off == 0 and ok == false when absent
@@ -146,6 +149,22 @@ static DevCol add_col16(ArenaBuilder& ab, const float* w, const float* bias, int
   d.b_off = ab.add(p.bias);
   d.ok = true;
   return d;
+}
+
+// lin16_kernel instantiations: (taps, channel groups per k-group)
+static bool lin16_shape_ok(int K, int Cin) {
+  const int J = (Cin + 31) / 32;
+  return (K == 3 && (J == 6 || J == 8 || J == 24)) || (K == 5 && J == 6);
+}
+// the second packing of a plain conv w[Cout][Cin][K] (add_conv(..., ROWS_PLAIN) made the first)
+static void add_lin16(ArenaBuilder& ab, DevConv& d, const float* w, const float* bias, int Cout, int Cin, int K) {
+  if (!lin16_shape_ok(K, Cin)) return;
+  PackedGate16 p = pack_lin16(
+      Cout, Cin, K, [&](int co, int ci, int k) { return w[((size_t)co * Cin + ci) * K + k]; }, [&](int co) { return bias[co]; },
+      bias != nullptr);
+  d.l16_J = p.J;
+  d.l16_w_off = ab.add(p.w);
+  d.l16_b_off = ab.add(p.bias);
 }
 
 struct Blob {

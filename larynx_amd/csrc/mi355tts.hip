@@ -206,6 +206,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
       TAKE(g, q + ".gamma", H);
       TAKE(be, q + ".beta", H);
       gm->pre_conv.push_back(add_conv(ab, w, b, H, H, h.prenet_kernel_size, ROWS_PLAIN));
+      add_lin16(ab, gm->pre_conv.back(), w, b, H, H, h.prenet_kernel_size);
       gm->pre_g.push_back(ab.add(g, H));
       gm->pre_b.push_back(ab.add(be, H));
     }
@@ -250,6 +251,8 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(c2, f + ".conv_2.bias", H);
     L.ffn1 = add_conv(ab, w1, c1, Fc, H, k, ROWS_PLAIN);
     L.ffn2 = add_conv(ab, w2, c2, H, Fc, k, ROWS_PLAIN);
+    add_lin16(ab, L.ffn1, w1, c1, Fc, H, k);
+    add_lin16(ab, L.ffn2, w2, c2, H, Fc, k);
     TAKE(g2, "encoder.encoder.norm_layers_2." + std::to_string(l) + ".gamma", H);
     TAKE(b2, "encoder.encoder.norm_layers_2." + std::to_string(l) + ".beta", H);
     L.g2 = ab.add(g2, H);
@@ -272,6 +275,8 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(bp, std::string("encoder.proj_w.proj.bias"), 1);
     gm->dp1 = add_conv(ab, w1, b1, Fd, H, k, ROWS_PLAIN);
     gm->dp2 = add_conv(ab, w2, b2, Fd, Fd, k, ROWS_PLAIN);
+    add_lin16(ab, gm->dp1, w1, b1, Fd, H, k);
+    add_lin16(ab, gm->dp2, w2, b2, Fd, Fd, k);
     gm->dpp = add_conv(ab, wp, bp, 1, Fd, 1, ROWS_PLAIN);
     gm->dpp_w = ab.add(wp, Fd);
     gm->dpp_b = ab.add(bp, 1);

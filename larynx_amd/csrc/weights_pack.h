@@ -168,6 +168,31 @@ inline PackedGate16 pack_gate16(int half, int Cin, int K, WGet wget, BGet bget, 
   return p;
 }
 
+// A fragments and biases for lin16_kernel (gate16.h): a plain conv w[rows][Cin][K] on 16-row tiles.  k-group g of 8 takes the
+// 4-channel groups g + 8 j (j < J); lane (m = l & 15, kq = l >> 4) of its step (j, tap) holds W[16 p + m][4 (g + 8 j) + kq][tap].
+template <typename WGet, typename BGet>
+inline PackedGate16 pack_lin16(int rows, int Cin, int K, WGet wget, BGet bget, bool has_bias) {
+  PackedGate16 p;
+  p.ptiles = (rows + 15) / 16;
+  p.J = (Cin + 31) / 32;
+  p.w.assign((size_t)p.ptiles * 8 * p.J * K * 64, 0.f);
+  p.bias.assign((size_t)p.ptiles * 16, 0.f);
+  for (int t = 0; t < p.ptiles; ++t)
+    for (int m = 0; m < 16; ++m) {
+      const int co = 16 * t + m;
+      if (co >= rows) continue;
+      if (has_bias) p.bias[(size_t)t * 16 + m] = bget(co);
+      for (int g = 0; g < 8; ++g)
+        for (int j = 0; j < p.J; ++j)
+          for (int kq = 0; kq < 4; ++kq) {
+            const int ci = 4 * (g + 8 * j) + kq;
+            if (ci >= Cin) continue;
+            for (int k = 0; k < K; ++k) p.w[((((size_t)t * 8 + g) * p.J + j) * K + k) * 64 + 16 * kq + m] = wget(co, ci, k);
+          }
+    }
+  return p;
+}
+
 // A fragments for the column-owner launches (coltile.h): a dense W[rows][K] on 16-row tiles of v_mfma_f32_16x16x4_f32,
 // [row tile][group of 4 k-steps][64 lanes][4]: element j of lane (m = l & 15, kq = l >> 4) is W[16 rt + m][16 q + 4 j + kq].
 // Rows and K zero-padded to multiples of 16; the bias to whole row tiles.

@@ -3,7 +3,9 @@ against the separate launches they replace (option `glow_fuse` off):
 
 * `glow_tail_kernel` — res_skip[last] + end + coupling + InvConvNear/ActNorm reverse + the next block's start
   (glow_tts/attentions.py:119-142, layers.py:138-162, :192-194, :238-272);
-* `oproj_ln_kernel`  — conv_o + residual + LayerNorm of an encoder layer (attentions.py:62-68).
+* `oproj_ln_kernel`  — conv_o + residual + LayerNorm of an encoder layer (attentions.py:62-68);
+* `lin16_kernel` (csrc/gate16.h) — the encoder's long-K convs (FFN, duration predictor, prenet) on 16-row tiles with the input
+  tile staged once.
 """
 import numpy as np
 import pytest
@@ -85,3 +87,19 @@ def test_shapes_outside_the_kernels_fall_back(emu_engine):
     refs, on, off = _both(emu_engine, hp, 71, (21,))
     np.testing.assert_allclose(on[0], refs[0], atol=5e-5, rtol=1e-4)
     np.testing.assert_allclose(off[0], refs[0], atol=5e-5, rtol=1e-4)
+
+
+def test_encoder_convs_on_16_row_tiles(emu_engine):
+    """The released voices' encoder widths: FFN 192 -> 768 -> 192 (k = 3; conv_2 is the 24-group instantiation on 16-column
+    tiles), duration predictor 192 -> 256 -> 256, prenet k = 5 — against the oracle and the generic 32-row tile; a ragged
+    batch with lengths on both sides of the 16- and 32-column seams."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=192, filter_channels=768, filter_channels_dp=256, n_blocks_dec=1,
+                        n_layers_enc=1, n_block_layers=1, mel_channels=8)
+    refs, on, off = _both(emu_engine, hp, 73, (35, 9, 17), batch=True)
+    for ref, a, b in zip(refs, on, off):
+        np.testing.assert_allclose(a, ref, atol=5e-5, rtol=1e-4)
+        np.testing.assert_allclose(b, ref, atol=5e-5, rtol=1e-4)
+        assert np.abs(a - b).max() < 2e-5
+    _, single = _run(emu_engine, hp, 73, (35, 9, 17), batch=False)
+    for a, b in zip(on, single):
+        assert np.array_equal(a, b)  # a row of a padded batch = its own batch-1 call
