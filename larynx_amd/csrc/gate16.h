@@ -168,8 +168,15 @@ struct Lin16Args {
   float* y;  // [B][rows][y_ld]
   long long y_bs;
   int y_ld;
-  const float* res;  // optional residual, geometry of y
+  const float* res;  // optional residual, geometry of y (rows < split only)
   int relu;
+  // rows >= split (a multiple of 16) go to the second output, re-based: y2[row - split] (+= when accum2) — the WaveNet
+  // res_skip conv's skip half (glow_tts/layers.py:154-160)
+  int split;
+  float* y2;
+  long long y2_bs;
+  int y2_ld;
+  int accum2;
 };
 
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J), NBLK = 16-column blocks per workgroup (1 or 2)
@@ -222,8 +229,13 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   const int erow = ty * 16 + (ethread ? ei : 0), et = t0 + en;
   const bool eok = ethread && erow < a.rows && et < L;
   const float ebias = a.bias[ty * 16 + (ethread ? ei : 0)];
+  const bool second = ty * 16 >= a.split;  // uniform per workgroup
   float eres = 0.f;
-  if (a.res) eres = a.res[(long long)b * a.y_bs + (long long)(eok ? erow : 0) * a.y_ld + (eok ? et : 0)];
+  if (!second) {
+    if (a.res) eres = a.res[(long long)b * a.y_bs + (long long)(eok ? erow : 0) * a.y_ld + (eok ? et : 0)];
+  } else if (a.accum2) {
+    eres = a.y2[(long long)b * a.y2_bs + (long long)(eok ? erow - a.split : 0) * a.y2_ld + (eok ? et : 0)];
+  }
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int e = tid + 512 * i;
@@ -272,8 +284,11 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
     for (int g = 0; g < 8; ++g) v += xs[g * (NBLK * 256) + src];
     v += ebias;
     v += eres;
-    if (a.relu) v = v > 0.f ? v : 0.f;
-    if (eok) a.y[(long long)b * a.y_bs + (long long)erow * a.y_ld + et] = v;
+    if (a.relu && !second) v = v > 0.f ? v : 0.f;
+    if (eok) {
+      if (!second) a.y[(long long)b * a.y_bs + (long long)erow * a.y_ld + et] = v;
+      else a.y2[(long long)b * a.y2_bs + (long long)(erow - a.split) * a.y2_ld + et] = v;
+    }
   }
 }
 

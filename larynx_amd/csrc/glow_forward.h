@@ -250,13 +250,13 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     }
     ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
     a.res = x;
-    CHECK(launch_conv(ctx, w, gm->pre_proj, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->pre_proj, a, B, Pmax, glow_tiles, enc_host_len));
   }
   for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
     const GlowLayer& L = gm->layers[l];
     {
       ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
-      CHECK(launch_conv(ctx, w, L.qkv, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.qkv, a, B, Pmax, glow_tiles, enc_host_len));
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -300,7 +300,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   }
   {  // proj_m and the duration predictor (models.py:133-139, 39-49)
     ConvArgs a = base_args(x, bsH, P, d_len, 1, xm, (long long)M * P, P, d_len, 1, 1, 0);
-    CHECK(launch_conv(ctx, w, gm->proj_m, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->proj_m, a, B, Pmax, glow_tiles, enc_host_len));
     float* d1 = ffn;
     float* d2 = ffn + (size_t)B * Fd * P;
     const long long bsD = (long long)Fd * P;
@@ -474,7 +474,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       r.y2_bs = bsD;
       r.y2_ld = F2;
       r.accum2 = j > 0;
-      CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
+      if (run_lin16(ctx, w, Bk.rs[j], r, A, B, F2max, KC_GLOW_DEC_CONV, dec_host_len) != 0)
+        CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       dil *= h.dilation_rate;
     }
     start_done = tail_done;

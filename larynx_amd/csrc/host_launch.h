@@ -672,15 +672,20 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_LIN16"); return e && std::atoi(e) != 0; }();
   // more tiles than this and the chunked 32-row tile fills the chip (longer rows, bigger batches)
   static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_LIN16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
-  if (off || !ctx->glow_fuse.load() || !c.l16_J || n_max <= 0) return 1;
+  static const bool no_k1 = [] { const char* e = std::getenv("MI355TTS_LIN16_NO_K1"); return e && std::atoi(e) != 0; }();
+  if (off || !ctx->glow_fuse.load() || !c.l16_J || n_max <= 0 || (c.K == 1 && no_k1)) return 1;
   const int PA = (a.pad + 3) & ~3;
   if ((PA - a.pad) + (c.K - 1) * a.dil > 16 || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
-  if (a.x2 || a.y2 || a.split < c.rows || a.alpha != 1.0f || a.accum || a.in_slope != 1.0f || (a.out_act != ACT_NONE && a.out_act != ACT_RELU))
-    return 1;
+  if (a.x2 || a.alpha != 1.0f || a.accum || a.in_slope != 1.0f || (a.out_act != ACT_NONE && a.out_act != ACT_RELU)) return 1;
+  const bool two = a.split < c.rows;  // second output for the rows >= split
+  if (two && (!a.y2 || a.split < 0 || a.split % 16)) return 1;
   const int nblk = c.l16_J >= 16 ? 1 : 2;
   const int TC = 16 * nblk;
   const int gx = (n_max + TC - 1) / TC, gy = (c.rows + 15) / 16;
   if ((long long)gx * gy * B > max_tiles) return 1;
+  // 1 x 1 convs: only the small launches (batch 1) — in config 4's padded batch of 8 the 840 16-row tiles of a res_skip conv
+  // measured 3 % faster alone and 1.2 % slower with 8 calls in flight than the 64-row tile (profiles/NOTES.md)
+  if (c.K == 1 && (long long)gx * gy * B > 512) return 1;
   Lin16Args g;
   std::memset(&g, 0, sizeof(g));
   g.x = a.x; g.x_bs = a.x_bs; g.x_ld = a.x_ld;
@@ -688,6 +693,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   g.len_mul = a.in_mul;
   g.w = arena + c.l16_w_off; g.bias = arena + c.l16_b_off; g.Cin = c.Cin; g.rows = c.rows; g.dil = a.dil; g.pad = a.pad;
   g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld; g.res = a.res; g.relu = a.out_act == ACT_RELU;
+  g.split = two ? a.split : (1 << 30); g.y2 = a.y2; g.y2_bs = a.y2_bs; g.y2_ld = a.y2_ld; g.accum2 = a.accum2;
   ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B);
   const dim3 grid(gx, gy, B);
   hipStream_t s = w->stream;
@@ -695,6 +701,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   else if (c.K == 3 && c.l16_J == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 8, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 3 && c.l16_J == 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 24, 1>), grid, dim3(512), 0, s, g);
   else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
+  else if (c.K == 1 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2>), grid, dim3(512), 0, s, g);
   else return 1;
   return 0;
 }

@@ -154,7 +154,7 @@ static DevCol add_col16(ArenaBuilder& ab, const float* w, const float* bias, int
 // lin16_kernel instantiations: (taps, channel groups per k-group)
 static bool lin16_shape_ok(int K, int Cin) {
   const int J = (Cin + 31) / 32;
-  return (K == 3 && (J == 6 || J == 8 || J == 24)) || (K == 5 && J == 6);
+  return (K == 3 && (J == 6 || J == 8 || J == 24)) || (K == 5 && J == 6) || (K == 1 && J == 6);
 }
 // the second packing of a plain conv w[Cout][Cin][K] (add_conv(..., ROWS_PLAIN) made the first)
 static void add_lin16(ArenaBuilder& ab, DevConv& d, const float* w, const float* bias, int Cout, int Cin, int K) {

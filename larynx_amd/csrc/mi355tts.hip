@@ -213,6 +213,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(w, std::string("encoder.pre.proj.weight"), (int64_t)H * H);
     TAKE(b, std::string("encoder.pre.proj.bias"), H);
     gm->pre_proj = add_conv(ab, w, b, H, H, 1, ROWS_PLAIN);
+    add_lin16(ab, gm->pre_proj, w, b, H, H, 1);
   }
   for (int l = 0; l < h.n_layers_enc; ++l) {
     GlowLayer L;
@@ -236,6 +237,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     std::memcpy(bqkv.data() + H, bk, sizeof(float) * H);
     std::memcpy(bqkv.data() + 2 * H, bv, sizeof(float) * H);
     L.qkv = add_conv(ab, wqkv.data(), bqkv.data(), 3 * H, H, 1, ROWS_PLAIN);
+    add_lin16(ab, L.qkv, wqkv.data(), bqkv.data(), 3 * H, H, 1);
     L.o = add_conv(ab, wo, bo, H, H, 1, ROWS_PLAIN);
     L.o16 = add_col16(ab, wo, bo, H, H);
     L.ek = ab.add(ek, (size_t)nrel * dk);
@@ -263,6 +265,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(w, std::string("encoder.proj_m.weight"), (int64_t)M * H);
     TAKE(b, std::string("encoder.proj_m.bias"), M);
     gm->proj_m = add_conv(ab, w, b, M, H, 1, ROWS_PLAIN);
+    add_lin16(ab, gm->proj_m, w, b, M, H, 1);
     TAKE(w1, std::string("encoder.proj_w.conv_1.weight"), (int64_t)Fd * H * k);
     TAKE(b1, std::string("encoder.proj_w.conv_1.bias"), Fd);
     TAKE(g1, std::string("encoder.proj_w.norm_1.gamma"), Fd);
@@ -314,6 +317,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
       B.in.push_back(add_conv(ab, wi, bi, 2 * H, H, h.kernel_size_dec, ROWS_PAIR, H));
       add_gate16(ab, B.in.back(), wi, bi, H, H, h.kernel_size_dec);
       B.rs.push_back(add_conv(ab, wr, br, rsn, H, 1, ROWS_PLAIN));
+      add_lin16(ab, B.rs.back(), wr, br, rsn, H, 1);
       if (j == h.n_block_layers - 1) B.t_rs = add_col16(ab, wr, br, H, H);
     }
     TAKE(we, cp + ".end.weight", (int64_t)C * H);
