@@ -65,8 +65,8 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
 
 // an encoder conv: the 16-row tile with the input staged once when the shape has one (lin16_kernel), else the generic tile
 static int launch_enc_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const DevConv& c, const ConvArgs& a, int B, int Pmax,
-                           int glow_tiles, int host_len) {
-  if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len) == 0) return 0;
+                           int glow_tiles, int host_len, bool solo_tiles = false) {
+  if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len, solo_tiles) == 0) return 0;
   return launch_conv(ctx, w, c, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, host_len);
 }
 
@@ -243,20 +243,20 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const float* cur = x;
     for (int i = 0; i < h.prenet_layers; ++i) {
       ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
-      CHECK(launch_enc_conv(ctx, w, gm, gm->pre_conv[i], a, B, Pmax, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, gm->pre_conv[i], a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
       cur = t2;
     }
     ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
     a.res = x;
-    CHECK(launch_enc_conv(ctx, w, gm, gm->pre_proj, a, B, Pmax, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->pre_proj, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
   }
   for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
     const GlowLayer& L = gm->layers[l];
     {
       ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
-      CHECK(launch_enc_conv(ctx, w, gm, L.qkv, a, B, Pmax, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.qkv, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -290,30 +290,30 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     {  // FFN, attentions.py:375-383
       ConvArgs a = base_args(x, bsH, P, d_len, 1, ffn, (long long)Fc * P, P, d_len, 1, 1, k / 2);
       a.out_act = ACT_RELU;
-      CHECK(launch_enc_conv(ctx, w, gm, L.ffn1, a, B, Pmax, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.ffn1, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
       ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
       c.res = x;
-      CHECK(launch_enc_conv(ctx, w, gm, L.ffn2, c, B, Pmax, glow_tiles, enc_host_len));
+      CHECK(launch_enc_conv(ctx, w, gm, L.ffn2, c, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
     }
   }
   {  // proj_m and the duration predictor (models.py:133-139, 39-49)
     ConvArgs a = base_args(x, bsH, P, d_len, 1, xm, (long long)M * P, P, d_len, 1, 1, 0);
-    CHECK(launch_enc_conv(ctx, w, gm, gm->proj_m, a, B, Pmax, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->proj_m, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     float* d1 = ffn;
     float* d2 = ffn + (size_t)B * Fd * P;
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
-    CHECK(launch_enc_conv(ctx, w, gm, gm->dp1, c1, B, Pmax, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->dp1, c1, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
       run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
     }
     ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
-    CHECK(launch_enc_conv(ctx, w, gm, gm->dp2, c2, B, Pmax, glow_tiles, enc_host_len));
+    CHECK(launch_enc_conv(ctx, w, gm, gm->dp2, c2, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     if (glow_fuse_on(ctx) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
       ProfScope ps(ctx, w, KC_SMALL, 0);
       hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d1, (const float*)nullptr,
@@ -474,7 +474,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       r.y2_bs = bsD;
       r.y2_ld = F2;
       r.accum2 = j > 0;
-      if (run_lin16(ctx, w, Bk.rs[j], r, A, B, F2max, KC_GLOW_DEC_CONV, dec_host_len) != 0)
+      if (run_lin16(ctx, w, Bk.rs[j], r, A, B, F2max, KC_GLOW_DEC_CONV, dec_host_len, call.solo_tiles) != 0)
         CHECK(launch_conv(ctx, w, Bk.rs[j], r, EPI_LINEAR, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));
       dil *= h.dilation_rate;
     }

@@ -668,7 +668,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
 // ---- a plain encoder conv on 16-row tiles with the whole input tile staged once (lin16_kernel, gate16.h).  Returns 1 when
 // this conv / launch is not one the kernel takes (the caller then launches the generic tile), 0 when launched.
 static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvArgs& a, const float* arena, int B, int n_max, int cls,
-                     int host_len) {
+                     int host_len, bool solo_tiles = false) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_LIN16"); return e && std::atoi(e) != 0; }();
   // more tiles than this and the chunked 32-row tile fills the chip (longer rows, bigger batches)
   static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_LIN16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
@@ -683,9 +683,11 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   const int TC = 16 * nblk;
   const int gx = (n_max + TC - 1) / TC, gy = (c.rows + 15) / 16;
   if ((long long)gx * gy * B > max_tiles) return 1;
-  // 1 x 1 convs: only the small launches (batch 1) — in config 4's padded batch of 8 the 840 16-row tiles of a res_skip conv
+  // 1 x 1 convs: not in big padded batches — in config 4's batch of 8 the 840 16-row tiles of a res_skip conv
   // measured 3 % faster alone and 1.2 % slower with 8 calls in flight than the 64-row tile (profiles/NOTES.md)
-  if (c.K == 1 && (long long)gx * gy * B > 512) return 1;
+  // (explicit batches only: a batch-1 call always takes this form, and so does a coalesced pass, whose rows must equal
+  // their batch-1 results whatever their lengths)
+  if (c.K == 1 && B > 1 && !solo_tiles && (long long)gx * gy * B > 512) return 1;
   Lin16Args g;
   std::memset(&g, 0, sizeof(g));
   g.x = a.x; g.x_bs = a.x_bs; g.x_ld = a.x_ld;
