@@ -177,14 +177,25 @@ struct Lin16Args {
   long long y2_bs;
   int y2_ld;
   int accum2;
+  // LN instantiations only: the input is LayerNorm'ed over its Cin channels per column first (glow_tts/layers.py:19-28:
+  // mean / biased variance, eps inside the sqrt), optionally ReLU'ed — the producer's `norm -> [relu] -> conv` chain
+  // without the LayerNorm launch.  `ln_out` (optional, geometry of x): the normalised columns of this tile are also written
+  // there by the workgroups of row tile 0 (the value is needed again as a residual).
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int ln_relu;
+  float* ln_out;
 };
 
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J), NBLK = 16-column blocks per workgroup (1 or 2)
-template <int K, int J, int NBLK>
+template <int K, int J, int NBLK, bool LN = false>
 __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   constexpr int TC = 16 * NBLK;  // columns per workgroup
   constexpr int XW = TC + 16;    // staged columns per channel row
   __shared__ float xs[(32 * J * XW > 2048 * NBLK) ? 32 * J * XW : 2048 * NBLK];  // [32 J][XW]; afterwards the partial tiles [8][NBLK][4][64]
+  __shared__ float lnred[LN ? 8 * 64 : 1];
+  static_assert(!LN || XW <= 64, "LayerNorm prologue: one lane per staged column");
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
   const int b = blockIdx.z;
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
@@ -236,6 +247,15 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   } else if (a.accum2) {
     eres = a.y2[(long long)b * a.y2_bs + (long long)(eok ? erow - a.split : 0) * a.y2_ld + (eok ? et : 0)];
   }
+  float lg[LN ? 4 * J : 1], lb[LN ? 4 * J : 1];  // LayerNorm gamma / beta of this wave's rows (kg, kg + 8, ...)
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < 4 * J; ++i) {
+      const int r = kg + 8 * i;
+      lg[i] = a.ln_gamma[r < a.Cin ? r : a.Cin - 1];
+      lb[i] = a.ln_beta[r < a.Cin ? r : a.Cin - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int e = tid + 512 * i;
@@ -250,6 +270,57 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
     if (e < NF4) reinterpret_cast<float4*>(xs)[e] = v;
   }
   __syncthreads();
+  if constexpr (LN) {
+    // ---- LayerNorm of the staged tile, column by column (halo columns included: the conv reads them; columns outside
+    // [0, L) stay zero = the conv's padding).  Lane = staged column, wave g = rows g, g + 8, ... (4 J of them, in registers)
+    constexpr int RW = 4 * J;
+    const int j = lane < XW ? lane : XW - 1, g = kg;
+    const int col = t0 - PA + j;
+    const bool cok = lane < XW && col >= 0 && col < L;
+    float v[RW];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int r = g + 8 * i;
+      v[i] = r < a.Cin ? xs[r * XW + j] : 0.f;
+      sum += v[i];
+    }
+    lnred[g * 64 + lane] = sum;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mean += lnred[q * 64 + lane];
+    mean /= (float)a.Cin;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float d = (g + 8 * i < a.Cin) ? v[i] - mean : 0.f;
+      sq += d * d;
+    }
+    lnred[g * 64 + lane] = sq;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) var += lnred[q * 64 + lane];
+    var /= (float)a.Cin;
+    const float rstd = rsqrtf(var + a.ln_eps);
+    const bool wout = a.ln_out != nullptr && ty == 0 && cok && j >= PA && j < PA + TC;  // this tile's own columns
+    float* ob = a.ln_out ? a.ln_out + (long long)b * a.x_bs + (cok ? col : 0) : nullptr;
+    if (cok) {
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int r = g + 8 * i;
+        if (r < a.Cin) {
+          float o = (v[i] - mean) * rstd * lg[i] + lb[i];
+          if (a.ln_relu) o = fmaxf(o, 0.f);
+          xs[r * XW + j] = o;
+          if (wout) ob[(long long)r * a.x_ld] = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- main loop: B fragment lane (n = lane & 15, kq = lane >> 4) = x[4 (g + 8 j) + kq][t0 + n + k dil - pad]
   gate_floatx4 acc[NBLK];

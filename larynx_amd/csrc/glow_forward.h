@@ -63,11 +63,36 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
   return 0;
 }
 
+// LayerNorm -> [ReLU] -> conv with the norm inside the conv launch (lin16_kernel's LN prologue) when the shape has one;
+// otherwise the LayerNorm launch (raw -> normed) and the conv on its output.  `normed` may be nullptr when nothing else
+// reads the normalised tensor AND the fused form is taken; the fallback needs a buffer: `scratch`.
+static int launch_ln_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const DevConv& c, ConvArgs a, const float* raw, float* normed,
+                          float* scratch, const float* gamma, const float* beta, int relu, int C, long long bs, int ld, const int* d_len,
+                          int B, int Pmax, int glow_tiles, int host_len, bool solo_tiles);
+
 // an encoder conv: the 16-row tile with the input staged once when the shape has one (lin16_kernel), else the generic tile
 static int launch_enc_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const DevConv& c, const ConvArgs& a, int B, int Pmax,
                            int glow_tiles, int host_len, bool solo_tiles = false) {
   if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len, solo_tiles) == 0) return 0;
   return launch_conv(ctx, w, c, a, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, host_len);
+}
+
+static int launch_ln_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const DevConv& c, ConvArgs a, const float* raw, float* normed,
+                          float* scratch, const float* gamma, const float* beta, int relu, int C, long long bs, int ld, const int* d_len,
+                          int B, int Pmax, int glow_tiles, int host_len, bool solo_tiles) {
+  static const bool no_ln = [] { const char* e = std::getenv("MI355TTS_LIN16_NO_LN"); return e && std::atoi(e) != 0; }();
+  if (!no_ln && glow_fuse_on(ctx)) {
+    Lin16Ln ln{gamma, beta, relu, normed};
+    a.x = raw;
+    if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len, solo_tiles, &ln) == 0) return 0;
+  }
+  float* dst = normed ? normed : scratch;
+  {
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    run_layernorm(w, raw, nullptr, gamma, beta, dst, C, bs, ld, d_len, B, Pmax, relu);
+  }
+  a.x = dst;
+  return launch_enc_conv(ctx, w, gm, c, a, B, Pmax, glow_tiles, host_len, solo_tiles);
 }
 
 struct GlowCall {
@@ -139,7 +164,7 @@ static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int 
   L.o_t1 = cv.take(sizeof(float) * (size_t)B * H * P);
   L.o_t2 = cv.take(sizeof(float) * (size_t)B * H * P);
   L.o_qkv = cv.take(sizeof(float) * (size_t)B * 3 * H * P);
-  L.o_ffn = cv.take(sizeof(float) * (size_t)B * std::max(Fc, 2 * Fd) * P);
+  L.o_ffn = cv.take(sizeof(float) * (size_t)B * std::max(Fc, 3 * Fd) * P);
   L.o_xm = cv.take(sizeof(float) * (size_t)B * M * P);
   L.o_logw = cv.take(sizeof(float) * (size_t)B * P);
   L.o_cum = cv.take(sizeof(int) * (size_t)B * P);
@@ -240,23 +265,39 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   }
   if (h.prenet) {
     // ConvReluNorm: conv -> LayerNorm -> ReLU (x3), then x + proj(.)  (layers.py:73-80)
-    const float* cur = x;
-    for (int i = 0; i < h.prenet_layers; ++i) {
-      ConvArgs a = base_args(cur, bsH, P, d_len, 1, t1, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
-      CHECK(launch_enc_conv(ctx, w, gm, gm->pre_conv[i], a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
-      ProfScope ps(ctx, w, KC_SMALL, 0);
-      run_layernorm(w, t1, nullptr, A + gm->pre_g[i], A + gm->pre_b[i], t2, H, bsH, P, d_len, B, Pmax, 1);
-      cur = t2;
+    // Each LayerNorm -> ReLU runs inside the conv that consumes it (launch_ln_conv): conv_0 writes its raw output, conv_i
+    // normalises conv_{i-1}'s, proj the last one's.  Raw outputs alternate between t1 and t2; qkv is the fallback's scratch.
+    float* raw = t1;
+    {
+      ConvArgs a = base_args(x, bsH, P, d_len, 1, raw, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
+      CHECK(launch_enc_conv(ctx, w, gm, gm->pre_conv[0], a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     }
-    ConvArgs a = base_args(cur, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
+    for (int i = 1; i < h.prenet_layers; ++i) {
+      float* out = raw == t1 ? t2 : t1;
+      ConvArgs a = base_args(raw, bsH, P, d_len, 1, out, bsH, P, d_len, 1, 1, h.prenet_kernel_size / 2);
+      CHECK(launch_ln_conv(ctx, w, gm, gm->pre_conv[i], a, raw, nullptr, qkv, A + gm->pre_g[i - 1], A + gm->pre_b[i - 1], 1, H, bsH, P, d_len,
+                           B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
+      raw = out;
+    }
+    ConvArgs a = base_args(raw, bsH, P, d_len, 1, x, bsH, P, d_len, 1, 1, 0);
     a.res = x;
-    CHECK(launch_enc_conv(ctx, w, gm, gm->pre_proj, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
+    const int last = h.prenet_layers - 1;
+    CHECK(launch_ln_conv(ctx, w, gm, gm->pre_proj, a, raw, nullptr, qkv, A + gm->pre_g[last], A + gm->pre_b[last], 1, H, bsH, P, d_len, B, Pmax,
+                         glow_tiles, enc_host_len, call.solo_tiles));
   }
+  bool ln2_pending = false;  // the previous layer's norm_layers_2 is still to be applied to t1 (the next qkv conv does it)
   for (int l = 0; l < h.n_layers_enc; ++l) {  // Encoder.forward, attentions.py:62-74
     const GlowLayer& L = gm->layers[l];
     {
       ConvArgs a = base_args(x, bsH, P, d_len, 1, qkv, 3 * bsH, P, d_len, 1, 1, 0);
-      CHECK(launch_enc_conv(ctx, w, gm, L.qkv, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
+      if (ln2_pending) {  // x = LayerNorm(t1) on the way in; stored too: it is the residual of this layer's conv_o and FFN
+        const GlowLayer& Lp = gm->layers[l - 1];
+        CHECK(launch_ln_conv(ctx, w, gm, L.qkv, a, t1, x, nullptr, A + Lp.g2, A + Lp.b2, 0, H, bsH, P, d_len, B, Pmax, glow_tiles,
+                             enc_host_len, call.solo_tiles));
+        ln2_pending = false;
+      } else {
+        CHECK(launch_enc_conv(ctx, w, gm, L.qkv, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
+      }
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -294,8 +335,12 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       ConvArgs c = base_args(ffn, (long long)Fc * P, P, d_len, 1, t1, bsH, P, d_len, 1, 1, k / 2);
       c.res = x;
       CHECK(launch_enc_conv(ctx, w, gm, L.ffn2, c, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
-      ProfScope ps(ctx, w, KC_SMALL, 0);
-      run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
+      if (l + 1 < h.n_layers_enc) {
+        ln2_pending = true;  // norm_layers_2 rides in the next layer's qkv conv
+      } else {
+        ProfScope ps(ctx, w, KC_SMALL, 0);
+        run_layernorm(w, t1, nullptr, A + L.g2, A + L.b2, x, H, bsH, P, d_len, B, Pmax, 0);
+      }
     }
   }
   {  // proj_m and the duration predictor (models.py:133-139, 39-49)
@@ -303,27 +348,26 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     CHECK(launch_enc_conv(ctx, w, gm, gm->proj_m, a, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     float* d1 = ffn;
     float* d2 = ffn + (size_t)B * Fd * P;
+    float* d3 = ffn + (size_t)2 * B * Fd * P;
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
     CHECK(launch_enc_conv(ctx, w, gm, gm->dp1, c1, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
-    {
-      ProfScope ps(ctx, w, KC_SMALL, 0);
-      run_layernorm(w, d1, nullptr, A + gm->dg1, A + gm->db1, d2, Fd, bsD, P, d_len, B, Pmax, 0);
-    }
-    ConvArgs c2 = base_args(d2, bsD, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
+    // norm_1 inside conv_2 (launch_ln_conv): d1 -> d2; d3 is the fallback's scratch
+    ConvArgs c2 = base_args(d1, bsD, P, d_len, 1, d2, bsD, P, d_len, 1, 1, k / 2);
     c2.out_act = ACT_RELU;
-    CHECK(launch_enc_conv(ctx, w, gm, gm->dp2, c2, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
+    CHECK(launch_ln_conv(ctx, w, gm, gm->dp2, c2, d1, nullptr, d3, A + gm->dg1, A + gm->db1, 0, Fd, bsD, P, d_len, B, Pmax, glow_tiles,
+                         enc_host_len, call.solo_tiles));
     if (glow_fuse_on(ctx) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
       ProfScope ps(ctx, w, KC_SMALL, 0);
-      hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d1, (const float*)nullptr,
-                         A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, 0, 0, 1e-4f, A + gm->dpp_w, A + gm->dpp_b, logw, (long long)P);
+      hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d2, (const float*)nullptr,
+                         A + gm->dg2, A + gm->db2, d1, Fd, bsD, P, d_len, 0, 0, 1e-4f, A + gm->dpp_w, A + gm->dpp_b, logw, (long long)P);
     } else {
       {
         ProfScope ps(ctx, w, KC_SMALL, 0);
-        run_layernorm(w, d1, nullptr, A + gm->dg2, A + gm->db2, d2, Fd, bsD, P, d_len, B, Pmax, 0);
+        run_layernorm(w, d2, nullptr, A + gm->dg2, A + gm->db2, d1, Fd, bsD, P, d_len, B, Pmax, 0);
       }
-      ConvArgs c3 = base_args(d2, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
+      ConvArgs c3 = base_args(d1, bsD, P, d_len, 1, logw, P, P, d_len, 1, 1, 0);
       CHECK(launch_conv(ctx, w, gm->dpp, c3, EPI_LINEAR, B, Pmax, KC_GLOW_ENC_CONV, nullptr, glow_tiles, enc_host_len));
     }
   }

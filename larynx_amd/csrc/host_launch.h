@@ -667,8 +667,16 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
 
 // ---- a plain encoder conv on 16-row tiles with the whole input tile staged once (lin16_kernel, gate16.h).  Returns 1 when
 // this conv / launch is not one the kernel takes (the caller then launches the generic tile), 0 when launched.
+// `ln` != nullptr: the conv's input is LayerNorm'ed first (lin16_kernel<..., true>): gamma / beta, ReLU behind the norm or not,
+// and where the normalised tensor is also stored (nullptr = nowhere)
+struct Lin16Ln {
+  const float* gamma;
+  const float* beta;
+  int relu;
+  float* out;
+};
 static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvArgs& a, const float* arena, int B, int n_max, int cls,
-                     int host_len, bool solo_tiles = false) {
+                     int host_len, bool solo_tiles = false, const Lin16Ln* ln = nullptr) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_LIN16"); return e && std::atoi(e) != 0; }();
   // more tiles than this and the chunked 32-row tile fills the chip (longer rows, bigger batches)
   static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_LIN16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
@@ -696,10 +704,18 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   g.w = arena + c.l16_w_off; g.bias = arena + c.l16_b_off; g.Cin = c.Cin; g.rows = c.rows; g.dil = a.dil; g.pad = a.pad;
   g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld; g.res = a.res; g.relu = a.out_act == ACT_RELU;
   g.split = two ? a.split : (1 << 30); g.y2 = a.y2; g.y2_bs = a.y2_bs; g.y2_ld = a.y2_ld; g.accum2 = a.accum2;
+  if (ln) {
+    const bool ln_shape = (c.K == 1 && c.l16_J == 6) || (c.K == 5 && c.l16_J == 6) || (c.K == 3 && c.l16_J == 8);
+    if (!ln_shape) return 1;
+    g.ln_gamma = ln->gamma; g.ln_beta = ln->beta; g.ln_eps = 1e-4f; g.ln_relu = ln->relu; g.ln_out = ln->out;
+  }
   ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B);
   const dim3 grid(gx, gy, B);
   hipStream_t s = w->stream;
-  if (c.K == 3 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 6, 2>), grid, dim3(512), 0, s, g);
+  if (ln && c.K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2, true>), grid, dim3(512), 0, s, g);
+  else if (ln && c.K == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2, true>), grid, dim3(512), 0, s, g);
+  else if (ln && c.K == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 8, 2, true>), grid, dim3(512), 0, s, g);
+  else if (c.K == 3 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 6, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 3 && c.l16_J == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 8, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 3 && c.l16_J == 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 24, 1>), grid, dim3(512), 0, s, g);
   else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
