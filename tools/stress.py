@@ -108,8 +108,12 @@ def main():
     ap.add_argument("--calls", type=int, default=1500)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--no-reserve", action="store_true", help="leave the workspaces grow-only (no mi355tts_reserve up front)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="mi355tts_set_option before anything runs, e.g. glow_coalesce=1 (the fused calls then share GlowTTS passes)")
     args = ap.parse_args()
     eng = Engine(0)
+    for kv in args.set_option:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.unload_leg > 0:
         print(json.dumps(unload_leg(eng, args.threads if args.threads != 4 else 6, args.unload_leg)))
         eng.close()
