@@ -80,9 +80,11 @@ def test_ragged_batch_rows_equal_single_calls(emu_engine):
         assert np.array_equal(a, b)
 
 
-def test_shapes_outside_the_kernels_fall_back(emu_engine):
-    """n_split = 8 has no fused InvConvNear: the block tails run as separate launches, conv_o + LayerNorm still fuses."""
-    hp = HP.GlowHParams(num_symbols=30, hidden_channels=64, filter_channels=32, filter_channels_dp=32, n_blocks_dec=2,
+@pytest.mark.parametrize("hidden", [64, 192])
+def test_shapes_outside_the_kernels_fall_back(emu_engine, hidden):
+    """n_split = 8 has no fused InvConvNear: the block tails run as separate launches, conv_o + LayerNorm still fuses.  At
+    hidden = 192 the last res_skip conv (all skip: split = 0) then runs on lin16_kernel with only its second output."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=hidden, filter_channels=32, filter_channels_dp=32, n_blocks_dec=2,
                         n_layers_enc=1, n_block_layers=2, mel_channels=8, n_split=8)
     refs, on, off = _both(emu_engine, hp, 71, (21,))
     np.testing.assert_allclose(on[0], refs[0], atol=5e-5, rtol=1e-4)
