@@ -780,6 +780,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
           }
           continue;
         }
+#ifndef MI355TTS_NO_UP2_PAIR  // (A/B builds only)
+        if (a.up == 2) {
+          // stride 2: registers (r, r + 1), r even, of a lane are the two phases of ONE output channel = two consecutive
+          // output samples; the lanes of a half-wave are consecutive q, so one 8-byte store per pair writes 256
+          // contiguous bytes per half-wave instead of two interleaved 4-byte stores at stride 8.  (4-byte aligned only:
+          // up_pad is odd for the k = 4 upsamplers; the hardware takes dword-aligned multi-dword stores.)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;  // even
+            if (row >= a.rows) continue;
+            const int co = row >> 1;
+            const int n0 = q * 2 - a.up_pad;
+            float* dst = a.y + (long long)b * a.y_bs + (long long)co * a.y_ld + n0;
+            const float v0 = acc[mb][nb][r] + bb[r], v1 = acc[mb][nb][r + 1] + bb[r + 1];
+            if (n0 >= 0 && n0 + 1 < Lout && row + 1 < a.rows) {
+              typedef float up_float2 __attribute__((ext_vector_type(2), aligned(4)));
+              *reinterpret_cast<up_float2*>(dst) = up_float2{v0, v1};
+            } else {
+              if (n0 >= 0 && n0 < Lout) dst[0] = v0;
+              if (row + 1 < a.rows && n0 + 1 >= 0 && n0 + 1 < Lout) dst[1] = v1;
+            }
+          }
+          continue;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
