@@ -364,6 +364,24 @@ __device__ __forceinline__ void conv_bf16_tile(const ConvArgs& a, const int tile
               for (int e = 0; e < 4; ++e)
                 if (n0 + e >= 0 && n0 + e < Lout) dst[e] = acc[mb][nb][4 * g4 + e] + bb[4 * g4 + e];
             }
+          } else if (a.up == 2) {
+            // stride 2: registers (e, e + 1), e even, are the two phases of one channel = two consecutive samples: one
+            // 8-byte (4-byte aligned) store per pair, as in conv_mfma.h
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const int row = row0 + e;  // even
+              if (row >= a.rows) continue;
+              const int n0 = q * 2 - a.up_pad;
+              float* dst = a.y + (long long)b * a.y_bs + (long long)(row >> 1) * a.y_ld + n0;
+              const float v0 = acc[mb][nb][4 * g4 + e] + bb[4 * g4 + e], v1 = acc[mb][nb][4 * g4 + e + 1] + bb[4 * g4 + e + 1];
+              if (n0 >= 0 && n0 + 1 < Lout && row + 1 < a.rows) {
+                typedef float up_float2 __attribute__((ext_vector_type(2), aligned(4)));
+                *reinterpret_cast<up_float2*>(dst) = up_float2{v0, v1};
+              } else {
+                if (n0 >= 0 && n0 < Lout) dst[0] = v0;
+                if (row + 1 < a.rows && n0 + 1 >= 0 && n0 + 1 < Lout) dst[1] = v1;
+              }
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
