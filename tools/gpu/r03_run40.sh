@@ -10,5 +10,5 @@ print('$1', 'utt/s', round(d['value'],1), 'lat', round(d['latency_ms_single_stre
 }
 for i in 1 2 3; do
   run base libmi355tts_base.so
-  run pair libmi355tts.so
-done | tee $O/ab_up2_pair.log
+  run defer libmi355tts.so
+done | tee $O/ab_defer_m128.log
