@@ -12,9 +12,10 @@
 //   oproj_ln_kernel   — conv_o of the encoder's attention + residual + LayerNorm (attentions.py:62-68, :205-212)
 //
 // Why column owners here and not in the WaveNet layers: these steps are 15-37 k MAC per column — a 16-column tile is
-// 1296 v_mfma_f32_16x16x4_f32 over four SIMDs (~5 us at one workgroup per CU) against 3 launches of 5.9-7.4 us each,
-// which are launch-latency chains (cold weights -> MFMA -> k-group reduction -> store) on a ~312-column problem.  The
-// gate convs (442 k MAC per column) would take 26 us on a column owner and stay row-tiled (gate16.h).
+// 1296 v_mfma_f32_16x16x4_f32 over four SIMDs (~5 us of matrix-pipe time at one workgroup per CU; the launch measures
+// 12 us, profiles/NOTES.md) against 3 launches of 5.9-7.4 us each, which are launch-latency chains (cold weights -> MFMA
+// -> k-group reduction -> store) on a ~312-column problem.  The gate convs (442 k MAC per column) would take 26 us on a
+// column owner and stay row-tiled (gate16.h).
 //
 // GEMM form: Y[R x 16] = W[R x K] X[K x 16].  A fragments pre-packed per lane (pack_col16: one float4 = four k-steps),
 // streamed from L2 through a register ring; X lives in LDS as [K][16] — the B fragment of k-step s is the 64

@@ -13,6 +13,9 @@
 // k-group g takes the 4-channel groups g, g + 8, ... with all their taps, its A fragments (pre-packed per lane, one
 // dword per MFMA) all requested at entry; two accumulators (column blocks) per wave make consecutive MFMAs
 // independent.  The 8 partial tiles meet in LDS, where thread (channel i, column n) finds its tanh and sigmoid rows.
+//
+// lin16_kernel (second half of this file) is the same tile with a plain epilogue for the other small-launch convs of
+// GlowTTS (FFN, duration predictor, prenet, 1 x 1 convs), optionally with the producer's LayerNorm as a prologue.
 #pragma once
 #include <hip/hip_runtime.h>
 
