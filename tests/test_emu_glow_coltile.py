@@ -105,3 +105,39 @@ def test_encoder_convs_on_16_row_tiles(emu_engine):
     _, single = _run(emu_engine, hp, 73, (35, 9, 17), batch=False)
     for a, b in zip(on, single):
         assert np.array_equal(a, b)  # a row of a padded batch = its own batch-1 call
+
+
+def test_launch_counts_of_the_fused_schedule(emu_engine):
+    """The fused schedule is the one that runs (a shape check that silently fell back to the separate launches would still pass
+    the value checks above): per utterance the decoder is 1 start + per block (layers gate convs + layers - 1 res_skip + 1
+    tail), the encoder has no LayerNorm launch left but the last norm_layers_2 and the duration predictor's norm_2 + proj."""
+    hp = HP.GlowHParams(num_symbols=30, hidden_channels=192, filter_channels=768, filter_channels_dp=256, n_blocks_dec=3,
+                        n_layers_enc=2, n_block_layers=4, mel_channels=80)
+    sd = synthetic.make_glow_state_dict(hp, seed=91)
+    g = emu_engine.load_glow(hp, sd)
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(92), 21, hp.num_symbols)
+    try:
+        counts = {}
+        for fuse in (1, 0):
+            emu_engine.set_option("glow_fuse", fuse)
+            emu_engine.glow_infer(g, ids, 0.0, 1.0).free()  # workspaces sized outside the counted call
+            emu_engine.set_profiling(True)
+            emu_engine.profile_reset()
+            emu_engine.glow_infer(g, ids, 0.0, 1.0).free()
+            prof = emu_engine.profile()
+            emu_engine.set_profiling(False)
+            counts[fuse] = {k: v["launches"] for k, v in prof.items()}
+    finally:
+        emu_engine.set_option("glow_fuse", 1)
+        emu_engine.set_profiling(False)
+        emu_engine.unload(g)
+    blocks, layers, enc = hp.n_blocks_dec, hp.n_block_layers, hp.n_layers_enc
+    assert counts[1]["conv_mfma.glow_decoder"] == 1 + blocks * (layers + (layers - 1) + 1)
+    assert counts[0]["conv_mfma.glow_decoder"] == blocks * (1 + 2 * layers + 1)
+    # encoder convs: prenet 3 + proj, per layer qkv + conv_o(+LN) + 2 FFN, proj_m, 2 duration-predictor convs
+    assert counts[1]["conv_mfma.glow_encoder"] == 4 + enc * 4 + 3
+    assert counts[0]["conv_mfma.glow_encoder"] == 4 + enc * 4 + 3 + 1  # + the duration predictor's proj as its own conv
+    # small kernels: embed, attention per layer, the last norm_layers_2, norm_2 + proj, duration, expand, mel_finalize ...
+    assert counts[1]["elementwise"] == 1 + enc + 1 + 1 + 1 + 1 + 1
+    # ... and, unfused, every LayerNorm: prenet 3, two per layer, two in the duration predictor
+    assert counts[0]["elementwise"] == 1 + enc + (3 + 2 * enc + 2) + 1 + 1 + 1

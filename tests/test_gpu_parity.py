@@ -323,6 +323,26 @@ def test_coalesced_calls_equal_their_solitary_results(gpu_engine):
             gpu_engine.set_precision(v, ffi.PRECISION_F32)
 
 
+def test_glowtts_launch_counts_on_the_device(gpu_engine):
+    """The fused GlowTTS schedule is the one that runs for the released voices' shape: 97 decoder launches (1 start + 12 x (4
+    gate convs + 3 res_skip + 1 tail)), 31 encoder conv launches, 12 small kernels per utterance — a shape check that silently
+    fell back to the separate launches (122 / 32 / 23) would still pass the value checks."""
+    (gsd, g), _ = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    ids = synthetic.synthetic_phoneme_ids(np.random.default_rng(3), 120, HP.LJSPEECH.num_symbols)
+    gpu_engine.glow_infer(g, ids, 0.667, 0.65, seed=1).free()
+    gpu_engine.set_profiling(True)
+    try:
+        gpu_engine.profile_reset()
+        gpu_engine.glow_infer(g, ids, 0.667, 0.65, seed=1).free()
+        prof = gpu_engine.profile()
+    finally:
+        gpu_engine.set_profiling(False)
+    hp = HP.LJSPEECH
+    assert prof["conv_mfma.glow_decoder"]["launches"] == 1 + hp.n_blocks_dec * (2 * hp.n_block_layers)
+    assert prof["conv_mfma.glow_encoder"]["launches"] == 4 + hp.n_layers_enc * 4 + 3
+    assert prof["elementwise"]["launches"] == 1 + hp.n_layers_enc + 5
+
+
 def test_long_utterance_and_three_resident_voices(gpu_engine):
     """BASELINE config 5 shape: three voices (en V=46, de V=54, fr V=42) resident at
     once, interleaved calls; plus a long (400-id) sentence at 'low' quality:
