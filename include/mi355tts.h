@@ -237,7 +237,9 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * (0/1, default 0) — while other calls are in flight, launch the members of a group one by one
  * (and, with "mrf_group" = 0, do not fork the chains onto side streams); "gate16", "glow_fuse", "mrf_small" (0/1, default 1)
  * — the small-launch kernels of gate16.h / coltile.h / mrf_small.h (0 = the generic tiles; same results up to summation
- * order); "glow_coalesce" (below).  The schedule options give the same bits under every setting. */
+ * order); "rb_conv" (0/1, default 1) — the grouped 128-row ResBlock launches on the continuous-stream tile of rb_conv.h
+ * (0 = the chunked tile of conv_mfma.h; same bits); "glow_coalesce" (below).  The schedule options give the same bits under
+ * every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 /* Option "glow_coalesce" (0/1, default 0): concurrent batch-1 mi355tts_synthesize calls (the reference's per-sentence
  * thread pool, larynx/__init__.py:146-157, 187-190) share GlowTTS passes — the callers waiting when a pass starts become

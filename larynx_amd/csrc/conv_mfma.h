@@ -33,6 +33,12 @@
 #ifndef CONV_STAMP
 #define CONV_STAMP(n)  // phase stamps of tools/probe/glow_conv_bench.hip
 #endif
+#ifndef CONV_WG_STAMP
+#define CONV_WG_STAMP(lin, which)  // workgroup begin / end stamps of tools/probe/rb_diag.hip
+#endif
+#ifndef CONV_CHUNK_STAMP
+#define CONV_CHUNK_STAMP(chunk, which)  // per-chunk phase stamps of tools/probe/rb_diag.hip
+#endif
 #ifndef MI355TTS_ARING
 #define MI355TTS_ARING 3  // depth of the A-fragment register ring (steps in flight + 1)
 #endif
@@ -258,6 +264,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) pre[i] = *reinterpret_cast<const float4*>(xb + off[i]);
+#ifndef MI355TTS_PROBE_NO_X2  // (probe builds only: the staging path without the MRF-average inputs)
     if (xb2) {  // wave-uniform: MRF average of the previous stage's chains, batched (this path waits)
       float4 t2[NE];
 #pragma unroll
@@ -288,6 +295,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
         pre[i].w = pre[i].w / a.in_div;
       }
     }
+#endif
   };
   auto lstore = [&](int buf, int chunk, const float4 (&pre)[NE]) {
     float4* dst = reinterpret_cast<float4*>(xs + buf * (CI_C * XW));
@@ -364,6 +372,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
   auto do_chunk = [&](int chunk, float4 (&pre_load)[NE], const float4 (&pre_store)[NE]) {
     const int buf = chunk & 1;
     const bool more = chunk < last_chunk;
+    CONV_CHUNK_STAMP(chunk, 0);
     if constexpr (PD1) {
       if (more) gload(chunk + 1, pre_load);
     } else {
@@ -440,8 +449,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
 #pragma unroll
         for (int i = 0; i < RD - 1; ++i) ar[i][mb] = rr[i][mb];
     }
+    CONV_CHUNK_STAMP(chunk, 1);
     if (more && !MI355TTS_ABLATE(a, 1)) lstore(buf ^ 1, chunk + 1, pre_store);
+    CONV_CHUNK_STAMP(chunk, 2);
     if (!MI355TTS_ABLATE(a, 4)) __syncthreads();
+    CONV_CHUNK_STAMP(chunk, 3);
   };
   if constexpr (PD1) {
     for (int chunk = 0; chunk < nchunks; ++chunk) do_chunk(chunk, preA, preA);
@@ -863,6 +875,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4
   const bool ragged = gridDim.z > 1;  // rows of different lengths: a row deals only its own tiles (see row_tiles)
   constexpr int T_T = WN * NB * 32;
   int tx, ty;
+  CONV_WG_STAMP(lin, 0);
   if (lin < g.off[1]) {
     const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), T_T) : g.gx[0];
     if (lin >= gx * g.gy[0]) return;
@@ -881,6 +894,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4
     xcd_tile_lin(l, gx, g.gy[2], tx, ty);
     conv_tile<K2, CI_C, MB, NB, WN, KS, H2, EPI_LINEAR, WM>(g.c[2], tx, ty, b, xs);
   }
+  CONV_WG_STAMP(lin, 1);
 }
 
 }  // namespace mi355tts

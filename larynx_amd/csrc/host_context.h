@@ -53,6 +53,7 @@ struct mi355tts_ctx {
   std::atomic<bool> glow_fuse{true};  // GlowTTS column-owner launches (coltile.h): block tails, conv_o + LayerNorm
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
+  std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
   // concurrent batch-1 mi355tts_synthesize calls share ONE GlowTTS pass (host_join.h): the callers waiting when a pass
   // starts become its rows.  Off by default: measured neutral to -1 % on the 'high' vocoder (profiles/NOTES.md)
   std::atomic<bool> glow_coalesce{false};

@@ -440,6 +440,22 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
                         (p0.shape == TILE_NB2 && p0.MB == 2) || p0.shape == TILE_M128;
   if (!shape_ok || !taps_ok) return 1;
   ProfScope ps(ctx, w, p0.cls, flop, s);
+  // The 128-row tile with the continuous matrix stream (rb_conv.h; same bits as the chunked tile) where the launch is
+  // what it was written for: plain ResBlock convs (bias, optional residual), taps 11 / 7 / 3, dilation within its halos.
+  static const bool rb_off = [] { const char* e = std::getenv("MI355TTS_NO_RB_CONV"); return e && std::atoi(e) != 0; }();
+  if (p0.shape == TILE_M128 && k0 == 11 && !rb_off && ctx->rb_conv.load()) {
+    bool rb_ok = true;
+    for (int i = 0; i < 3; ++i) {
+      const ConvArgs& a = g.c[i];
+      const int K = i == 0 ? 11 : i == 1 ? 7 : 3, halo = i == 0 ? RbCfg<11>::HALO : i == 1 ? RbCfg<7>::HALO : RbCfg<3>::HALO;
+      rb_ok = rb_ok && !a.x2 && !a.x3 && a.bias && a.alpha == 1.0f && !a.accum && a.out_act == ACT_NONE && a.split >= a.rows && !a.y2 &&
+              a.rows % 128 == 0 && (K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= halo;
+    }
+    if (rb_ok) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), grid, dim3(256), 0, s, g);
+      return 0;
+    }
+  }
   if (k0 == 11) return launch_group_k<11, 7, 3>(s, p0.MB, p0.shape, grid, g);
   return launch_group_k<7, 5, 3>(s, p0.MB, p0.shape, grid, g);
 }

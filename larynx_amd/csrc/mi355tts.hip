@@ -26,6 +26,7 @@
 
 #include "../../include/mi355tts.h"
 #include "conv_mfma.h"
+#include "rb_conv.h"
 #include "resblock_pair.h"
 #include "conv_bf16.h"
 #include "resblock_pair_bf16.h"
@@ -1146,6 +1147,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "mrf_group") == 0) {
     ctx->mrf_group = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "rb_conv") == 0) {
+    ctx->rb_conv = value != 0;
     return 0;
   }
   if (std::strcmp(name, "serial_branches") == 0) {

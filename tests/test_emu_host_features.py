@@ -351,3 +351,30 @@ def test_128_row_tile_for_the_upsampler(emu_engine, monkeypatch):
         y = emu_engine.conv_transpose1d(x, w, b, stride=u, in_slope=0.1)
         ref = nn_np.conv_transpose1d(nn_np.leaky_relu(x[0], 0.1), w, b, stride=u, padding=(K - u) // 2)
         np.testing.assert_allclose(y[0], ref, rtol=1e-4, atol=5e-5)
+
+
+def test_continuous_stream_tile_equals_the_chunked_tile(emu_engine, monkeypatch):
+    """`rb_group_kernel` (rb_conv.h: four-buffer LDS ring, mid-chunk barrier, no chunk seam) runs the grouped 128-row ResBlock
+    launches by default; option "rb_conv" = 0 sends the same launches to the chunked tile of conv_mfma.h.  Same fragment
+    streams and accumulation order: the waveforms are the same bits, rows of different lengths and a tile-edge length included."""
+    monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)), num_mels=16)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=93)
+    v = emu_engine.load_hifigan(hp, sd)
+    rng = np.random.default_rng(12)
+    try:
+        for frames in ([64], [70, 33], [16]):
+            F = max(frames)
+            mel = (0.5 + 0.1 * rng.standard_normal((len(frames), hp.num_mels, F))).astype(np.float32)
+            mb = emu_engine.mel_from_numpy(mel, np.array(frames, np.int32))
+            new, _ = emu_engine.hifigan_infer(v, mb)
+            emu_engine.set_option("rb_conv", 0)
+            try:
+                old, _ = emu_engine.hifigan_infer(v, mb)
+            finally:
+                emu_engine.set_option("rb_conv", 1)
+            assert np.array_equal(new, old)
+            assert np.isfinite(new).all() and np.abs(new).max() > 1e-3
+    finally:
+        emu_engine.unload(v)

@@ -110,3 +110,81 @@ def test_two_rank_gloo_matches_single_process(emu_library, emu_engine, tmp_path)
         _, i16 = emu_engine.hifigan_infer(v, mel, want_float=False)
         n = int(mel.frames[0]) * HP.TINY_HIFIGAN.hop
         assert np.array_equal(merged[i], i16[0, :n])
+
+
+def test_lpt_over_eight_ranks_balances_config3():
+    """BASELINE config 3 as `bench.py` shards it on an 8-GPU node: 256 utterances, P ~ clip(N(120, 15), 60, 200), LPT over 8
+    ranks — every utterance exactly once, 32 per rank, and the heaviest rank within 2 % of the mean load."""
+    rng = np.random.default_rng(1234)  # the recipe of bench.config3_ids (SURVEY.md §8(d))
+    lengths = [int(p) for p in np.clip(np.rint(rng.normal(120.0, 15.0, 256)), 60, 200)]
+    shards = lpt_assign(lengths, 8)
+    assert sorted(i for s in shards for i in s) == list(range(256))
+    loads = [sum(lengths[i] for i in s) for s in shards]
+    assert max(loads) * 8 / sum(loads) <= 1.02, loads
+    assert all(len(s) == 32 for s in shards), [len(s) for s in shards]
+    for w in (2, 4):  # the driver's other scaling points
+        loads = [sum(lengths[i] for i in s) for s in lpt_assign(lengths, w)]
+        assert max(loads) * w / sum(loads) <= 1.02
+
+
+def _worker8(rank, world, port, lib, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch.distributed as dist
+
+    from larynx_amd import hparams as HP
+    from larynx_amd import sharding, synthetic
+    from larynx_amd.engine import Engine
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = Engine(0, library_path=lib)
+    gsd = vsd = None
+    if rank == 0:  # only rank 0 has the checkpoint
+        gsd = synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7)
+        vsd = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7)
+    g, v = sharding.load_models_broadcast(eng, HP.TINY_GLOW, HP.TINY_HIFIGAN, gsd, vsd, device="cpu")
+    rows = _rows8()
+    local = sharding.synthesize_shard(eng, g, v, rows, rank, world, noise_scale=0.667, seed=900)
+    assert sorted(local) == sharding.lpt_assign([len(r) for r in rows], world)[rank]
+    merged = sharding.gather_in_order(local, len(rows))
+    if rank == 0:
+        np.savez(Path(out_dir) / "merged8.npz", *merged)
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def _rows8():
+    from larynx_amd import hparams as HP
+    from larynx_amd import synthetic
+
+    # config 3's length distribution scaled to the emulator's sizes: 20 utterances over 8 ranks (2-3 per rank)
+    rng = np.random.default_rng(1234)
+    lens = np.clip(np.rint(rng.normal(12.0, 1.5, 20)), 6, 20).astype(int)
+    return [synthetic.synthetic_phoneme_ids(rng, int(p), HP.TINY_GLOW.num_symbols) for p in lens]
+
+
+def test_eight_rank_gloo_matches_single_process(emu_library, emu_engine, tmp_path):
+    """The 8-GPU job of BASELINE config 3 on CPU: world size 8 (gloo), weight broadcast from rank 0, LPT shards over 8
+    bins, device noise ON with utterance-keyed streams, ordered gather from 8 ranks — equal to one process, bit for bit."""
+    import torch.multiprocessing as mp
+
+    from larynx_amd import hparams as HP
+    from larynx_amd import sharding, synthetic
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker8, args=(8, port, str(emu_library), str(tmp_path)), nprocs=8, join=True)
+    rows = _rows8()
+    z = np.load(tmp_path / "merged8.npz")
+    merged = [z[f"arr_{i}"] for i in range(len(rows))]
+    g = emu_engine.load_glow(HP.TINY_GLOW, synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7))
+    v = emu_engine.load_hifigan(HP.TINY_HIFIGAN, synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7))
+    solo = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=900)
+    shards = sharding.lpt_assign([len(r) for r in rows], 8)
+    assert all(2 <= len(s) <= 3 for s in shards)
+    for i in range(len(rows)):
+        assert np.array_equal(merged[i], solo[i]), i
