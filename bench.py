@@ -41,8 +41,9 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, f32 MFMA = f32 vector peak
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 SAMPLE_RATE = 22050
-ROUND = "r03"
+ROUND = "r04"
 
 
 def algorithmic_flop(P: int, F: float, quality: str = "high") -> float:
@@ -214,7 +215,7 @@ def config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_
 
     def call(i, slot=0):
         fr = eng.synthesize_raw(g, v, ids_dev.data_ptr(), lens, ld, 0.667, length_scale, wav_f32[slot].data_ptr(),
-                                wav_i16[slot].data_ptr(), max_samples, seed=4000 + i, audio_settings=audio, flags=flags)
+                                wav_i16[slot].data_ptr(), max_samples, seed=4000 + 8 * i, audio_settings=audio, flags=flags)  # a batch of 8 consumes the streams seed .. seed + 7
         return fr
 
     def run(n, threads):
@@ -576,6 +577,49 @@ def main():
         eng.set_option("glow_coalesce", 0)
         run_steps(0, max(W, conc))
     t_dn = timed(lambda: run_steps(W, n_utts, denoiser=0.005), max(3, repeats // 3)) if dn_ok else [float("nan")]
+    # host CPU seconds (all threads of this process) over one more pass of the headline region: what a rank costs the host
+    # per utterance — the one term of the 1 -> 8 GPU curve that the ranks share (8 ranks x `conc` threads on one host)
+    barrier()
+    c0, w0 = time.process_time(), time.perf_counter()
+    run_steps(W, n_utts)
+    barrier()
+    host_cpu_s, host_wall_s = time.process_time() - c0, time.perf_counter() - w0
+    # what GlowTTS costs UNDER LOAD: the same K steps with the acoustic model taken out — every call is the vocoder alone on
+    # the device-resident mel GlowTTS produced for that utterance (same in-flight count, same buffers); the difference to the
+    # headline region is GlowTTS's price per utterance when its launches compete with other calls' vocoder launches
+    t_voc = None
+    if B == 1 and not args.tiny:
+        mels = {i: eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, args.length_scale, seed=1234 + i, audio_settings=s,
+                                      flags=ffi.IN_DEVICE) for i in range(W, n_utts)}
+        if mels:
+            def voc_step(i, slot):
+                eng.hifigan_infer_raw(v, mels[i], wav_f32[slot].data_ptr(), wav_i16[slot].data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
+
+            def run_voc():
+                if pool is None:
+                    for i in range(W, n_utts):
+                        voc_step(i, 0)
+                    return
+                import queue
+
+                q = queue.SimpleQueue()
+                for i in range(W, n_utts):
+                    q.put(i)
+
+                def work(slot):
+                    while True:
+                        try:
+                            i = q.get_nowait()
+                        except queue.Empty:
+                            return
+                        voc_step(i, slot)
+
+                list(pool.map(work, range(conc)))
+
+            run_voc()
+            t_voc = timed(run_voc, max(3, repeats // 3))
+            for m_ in mels.values():
+                m_.free()
 
     def med(x):
         return float(np.median(x))
@@ -602,7 +646,8 @@ def main():
         half = (med(h_flight), med(h_single), hprof["conv_mfma.hifigan_resblock"])
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
-                          half[0] if half else 0.0, half[1] if half else 0.0, med(t_flight_nc)], dtype=torch.float64, device=red_dev)
+                          half[0] if half else 0.0, half[1] if half else 0.0, med(t_flight_nc), med(t_voc) if t_voc else 0.0,
+                          host_cpu_s, host_wall_s], dtype=torch.float64, device=red_dev)
     per_rank = [[float(stats[0]), float(stats[1])]]  # this rank's (in-flight, single-stream) seconds per K-step region
     if use_dist:
         gathered = [None] * world
@@ -616,7 +661,8 @@ def main():
         stats = mx
     else:
         total_frames = float(frames)
-    dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single, dt_flight_nc = (float(x) for x in stats)
+    (dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single, dt_flight_nc, dt_voc,
+     host_cpu_max, host_wall_max) = (float(x) for x in stats)
 
     # ---- BASELINE config 3: 256 utterances, LPT-sharded over the ranks, ordered gather (strong scaling)
     c3 = None
@@ -802,6 +848,19 @@ def main():
             "rtf_single_stream": dt_single * world / audio_s,
             "x_realtime_single_stream": audio_s / (dt_single * world),
             "end_to_end_tflops_per_gpu": flop_utt * K * B / dt_flight / 1e12,
+            # (max over ranks) host CPU time of one pass of the headline region / its utterances: all threads of the rank's
+            # process — the Python callers, ctypes, the HIP runtime's launch path (~170 launches per utterance)
+            "host_cpu_ms_per_utterance": 1e3 * host_cpu_max / (K * B),
+            "host_cpu_cores_busy_per_rank": host_cpu_max / host_wall_max if host_wall_max > 0 else None,
+            "glow_under_load_ms": None if dt_voc <= 0 else 1e3 * (dt_flight - dt_voc) / K,
+            "vocoder_only_under_load": None if dt_voc <= 0 else {
+                "what": "the headline region with GlowTTS taken out: the same K utterances, the same calls in flight, each call the vocoder "
+                        "alone (mi355tts_hifigan_infer_padded) on the device-resident mel GlowTTS produced for it; "
+                        "glow_under_load_ms = ms_per_step - this = what the acoustic model costs per utterance when its ~140 small launches "
+                        "compete with other calls' vocoder launches (alone it takes latency_ms_single_stream minus the vocoder's share)",
+                "ms_per_step": 1e3 * dt_voc / K,
+                "utterances_per_sec": world * K * B / dt_voc,
+            },
             "glow_coalescing": None if not (conc > 1 and B == 1) else {
                 "what": "option glow_coalesce = 1 (default 0): concurrent batch-1 calls share GlowTTS passes — the callers waiting when a "
                         "pass starts become the rows of one padded batch (csrc/host_join.h); bit-identical results "
@@ -831,6 +890,21 @@ def main():
                 "x_realtime_per_gpu": audio_s / (dt_half_flight * world),
                 "resblock_class_ms_per_step": half[2]["ms"] / K,
                 "resblock_class_f32_equivalent_tflops": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 if half[2]["ms"] > 0 else None,
+                # the split mode issues THREE bf16 MFMAs per f32 product (hi*hi + hi*lo + lo*hi): the matrix pipes do 3x the
+                # algorithmic FLOPs, and that executed rate is what is priced against the dense bf16 peak
+                "roofline": None if half[2]["ms"] <= 0 else {
+                    "kernel": "HiFi-GAN ResBlock launches in the split-bf16 mode: conv_bf16_group_kernel (256/128-channel stages) + "
+                              "pair16_group_kernel (fused conv pairs, 64/32-channel stages), HIP events per launch, single stream",
+                    "bound": "mfma",
+                    "achieved": 3.0 * half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12,
+                    "peak": BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": 3.0 * half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                    "note": "executed bf16 MFMA work (3 x the algorithmic f32 FLOPs) / dense bf16 peak; the f32-equivalent rate above is what a "
+                            "caller sees; PMC of these kernels: profiles/r04_bf16x3_pmc_by_kernel.csv",
+                    "launches": half[2]["launches"],
+                    "avg_launch_us": 1e3 * half[2]["ms"] / max(1, half[2]["launches"]),
+                },
             },
             "weight_broadcast_seconds": broadcast_s if use_dist else None,
             "per_rank": {

@@ -131,7 +131,9 @@ int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision);
  * "input" / "input_lengths"), scales as in the reference's "scales" input.
  * noise: optional N(0,1) tensor [B][mel_channels][noise_ld] standing in for
  * torch.randn_like (glow_tts/models.py:348) — parity mode; NULL draws from a
- * counter-based generator keyed by `seed` (row b of a batch: seed + b).  `audio` (optional) additionally
+ * counter-based generator keyed by `seed` (row b of a batch: the stream seed + b — a batched call consumes the B
+ * consecutive streams seed .. seed + B - 1, so successive batched calls must advance `seed` by at least B, or pass explicit
+ * per-row seeds to mi355tts_glow_infer_rows, to draw independent fields).  `audio` (optional) additionally
  * produces the vocoder-input mel (the three numpy transforms of _sentence_task).
  * The frame count is data dependent; the result stays on the device. */
 int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,

@@ -16,13 +16,13 @@ static int run_layernorm(Worker* w, const float* x, const float* res, const floa
 
 // ---- column-owner launches (coltile.h).  Each returns 1 when the shape is not one the kernel takes (the caller then runs
 // the separate launches), 0 when launched.
-static bool glow_fuse_on(mi355tts_ctx* ctx) {
+static bool glow_fuse_on(const Worker* w) {  // the option as the call saw it at its start (glow_run)
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GLOW_FUSE"); return e && std::atoi(e) != 0; }();
-  return !off && ctx->glow_fuse.load();
+  return !off && w->o_glow_fuse;
 }
 static int run_oproj_ln(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const GlowLayer& L, const float* att, float* x, int H,
                         long long bs, int ld, const int* d_len, int host_len, int B, int Pmax) {
-  if (!glow_fuse_on(ctx) || !L.o16.ok || H > COL_MAXROWS || ld % 4 || Pmax <= 0) return 1;
+  if (!glow_fuse_on(w) || !L.o16.ok || H > COL_MAXROWS || ld % 4 || Pmax <= 0) return 1;
   const float* A = gm->arena;
   OprojLnArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -41,7 +41,7 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
                          int B, int F2max) {
   const mi355tts_glow_hparams& h = gm->hp;
   const int H = h.hidden_channels, half = h.mel_channels * h.n_sqz / 2;
-  if (!glow_fuse_on(ctx) || !Bk.t_rs.ok || !Bk.t_end.ok || !Bk.t_st.ok || (next && !next->t_st.ok) || h.n_split != 4 || (half % 2) || F2 % 4 ||
+  if (!glow_fuse_on(w) || !Bk.t_rs.ok || !Bk.t_end.ok || !Bk.t_st.ok || (next && !next->t_st.ok) || h.n_split != 4 || (half % 2) || F2 % 4 ||
       F2max <= 0)
     return 1;
   const float* A = gm->arena;
@@ -81,7 +81,7 @@ static int launch_ln_conv(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, con
                           float* scratch, const float* gamma, const float* beta, int relu, int C, long long bs, int ld, const int* d_len,
                           int B, int Pmax, int glow_tiles, int host_len, bool solo_tiles) {
   static const bool no_ln = [] { const char* e = std::getenv("MI355TTS_LIN16_NO_LN"); return e && std::atoi(e) != 0; }();
-  if (!no_ln && glow_fuse_on(ctx)) {
+  if (!no_ln && glow_fuse_on(w)) {
     Lin16Ln ln{gamma, beta, relu, normed};
     a.x = raw;
     if (run_lin16(ctx, w, c, a, gm->arena, B, Pmax, KC_GLOW_ENC_CONV, host_len, solo_tiles, &ln) == 0) return 0;
@@ -208,6 +208,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   const mi355tts_audio_settings* audio = call.audio;
   const uint32_t flags = call.flags;
   hipStream_t s = w->stream;
+  w->o_glow_fuse = ctx->glow_fuse.load();  // one read per call: the launch helpers below use the snapshot
+  w->o_gate16 = ctx->gate16.load();
   const float* A = gm->arena;
   const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int k = h.kernel_size, nh = h.n_heads;
@@ -358,7 +360,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     c2.out_act = ACT_RELU;
     CHECK(launch_ln_conv(ctx, w, gm, gm->dp2, c2, d1, nullptr, d3, A + gm->dg1, A + gm->db1, 0, Fd, bsD, P, d_len, B, Pmax, glow_tiles,
                          enc_host_len, call.solo_tiles));
-    if (glow_fuse_on(ctx) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
+    if (glow_fuse_on(w) && Fd <= 256) {  // norm_2 and proj (1 x 1, Fd -> 1) in one launch
       ProfScope ps(ctx, w, KC_SMALL, 0);
       hipLaunchKernelGGL(layernorm16_kernel, dim3((Pmax + 15) / 16, B), dim3(256), 0, w->stream, d2, (const float*)nullptr,
                          A + gm->dg2, A + gm->db2, d1, Fd, bsD, P, d_len, 0, 0, 1e-4f, A + gm->dpp_w, A + gm->dpp_b, logw, (long long)P);

@@ -31,6 +31,9 @@ struct Worker {
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_join[2] = {nullptr, nullptr};
+  // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
+  // a mi355tts_set_option from another thread never changes a call's schedule half way through)
+  bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true;
 };
 
 struct mi355tts_ctx {
@@ -42,7 +45,8 @@ struct mi355tts_ctx {
   std::vector<Worker*> free_workers;
   std::vector<Worker*> all_workers;
   // option flags: written by mi355tts_set_option / _set_profiling while calls are in flight on other threads -> atomics;
-  // a call reads each flag ONCE at its start (hifigan_run) so one call never mixes schedules
+  // a call reads each flag ONCE at its start (glow_run / hifigan_run copy them: locals, and Worker::o_* for the launch
+  // helpers) so one call never mixes schedules
   std::atomic<bool> profiling{false};
   std::atomic<bool> serial_branches{false};
   // calls currently holding a worker; with "adaptive_schedule" on and more than one in flight the vocoder
@@ -50,7 +54,9 @@ struct mi355tts_ctx {
   std::atomic<int> active_calls{0};
   std::atomic<bool> adaptive_schedule{false};
   std::atomic<bool> gate16{true};     // GlowTTS WaveNet gate convs on 16-row tiles (gate16.h) when the launch is small
-  std::atomic<bool> glow_fuse{true};  // GlowTTS column-owner launches (coltile.h): block tails, conv_o + LayerNorm
+  // GlowTTS column-owner launches (coltile.h: block tails, conv_o + LayerNorm) AND the whole-tile-in-LDS convs of
+  // gate16.h's lin16_kernel (FFN / duration predictor / prenet / 1 x 1 convs, LayerNorm prologues): 0 = the generic tiles
+  std::atomic<bool> glow_fuse{true};
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
@@ -60,7 +66,7 @@ struct mi355tts_ctx {
   std::mutex join_mu;
   std::condition_variable join_cv;
   std::vector<struct GlowJoinReq*> join_q;
-  bool join_busy = false;
+  std::vector<const struct GlowJoinReq*> join_leaders;  // the leaders of the passes in flight (under join_mu)
   long long join_passes = 0, join_rows = 0;  // under join_mu
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams

@@ -23,7 +23,7 @@ struct GlowBatch {
   hipEvent_t ready = nullptr;   // recorded on the leader's stream behind the pass (nullptr for a one-row pass)
   int device = 0;
   ~GlowBatch() {
-    hipSetDevice(device);
+    DeviceScope ds(device);
     if (ready) {
       hipEventSynchronize(ready);  // nothing may still write the blocks that go back to the pool
       hipEventDestroy(ready);
@@ -47,6 +47,7 @@ struct GlowJoinReq {
   int rc = 0;
   std::string err;
   bool done = false;
+  bool solo_retry = false;  // the shared pass failed (e.g. ANOTHER row hit the frame cap): this caller runs a pass of its own
 };
 
 constexpr int GLOW_JOIN_MAX_ROWS = 16;
@@ -106,6 +107,9 @@ static void glow_join_run(mi355tts_ctx* ctx, Worker* w, std::vector<GlowJoinReq*
     rows[b]->err = msg;
     rows[b]->row = b;
     if (rc == 0) rows[b]->batch = batch;
+    // a resource failure of a SHARED pass says nothing about a rider's own request: each rider (the leader included)
+    // then runs a solitary pass and reports what that one returns
+    rows[b]->solo_retry = rc != 0 && n > 1;
   }
   // on failure `batch` dies here: its destructor waits for whatever the pass queued before the blocks go back to the pool
   if (rc != 0 && w->stream) hipStreamSynchronize(w->stream);
@@ -117,9 +121,13 @@ static int glow_join(mi355tts_ctx* ctx, Worker* w, GlowJoinReq& req) {
   std::unique_lock<std::mutex> lk(ctx->join_mu);
   ctx->join_q.push_back(&req);
   while (!req.done) {
-    if (!ctx->join_busy) {
+    // "busy" is per compatibility class (model + scales + audio settings + id residency): a caller whose request no pass
+    // in flight could have taken leads its own pass at once instead of sleeping until an unrelated leader returns
+    bool busy = false;
+    for (const GlowJoinReq* l : ctx->join_leaders) busy = busy || glow_join_compatible(*l, req);
+    if (!busy) {
       // lead: this request plus every compatible one that is waiting, in arrival order
-      ctx->join_busy = true;
+      ctx->join_leaders.push_back(&req);
       std::vector<GlowJoinReq*> rows{&req};
       std::vector<GlowJoinReq*> rest;
       for (GlowJoinReq* r : ctx->join_q) {
@@ -134,13 +142,17 @@ static int glow_join(mi355tts_ctx* ctx, Worker* w, GlowJoinReq& req) {
       for (GlowJoinReq* r : rows) r->done = true;
       ctx->join_passes += 1;
       ctx->join_rows += (long long)rows.size();
-      ctx->join_busy = false;
+      ctx->join_leaders.erase(std::find(ctx->join_leaders.begin(), ctx->join_leaders.end(), &req));
       ctx->join_cv.notify_all();
       break;
     }
     ctx->join_cv.wait(lk);
   }
   lk.unlock();
+  if (req.solo_retry) {  // outside the queue: a pass of this request alone, on this caller's own worker
+    std::vector<GlowJoinReq*> self{&req};
+    glow_join_run(ctx, w, self);
+  }
   if (req.rc != 0) return fail(req.rc, "%s", req.err.c_str());
   return 0;
 }

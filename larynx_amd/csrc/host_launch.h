@@ -443,7 +443,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   // The 128-row tile with the continuous matrix stream (rb_conv.h; same bits as the chunked tile) where the launch is
   // what it was written for: plain ResBlock convs (bias, optional residual), taps 11 / 7 / 3, dilation within its halos.
   static const bool rb_off = [] { const char* e = std::getenv("MI355TTS_NO_RB_CONV"); return e && std::atoi(e) != 0; }();
-  if (p0.shape == TILE_M128 && k0 == 11 && !rb_off && ctx->rb_conv.load()) {
+  if (p0.shape == TILE_M128 && k0 == 11 && !rb_off && w->o_rb_conv) {
     bool rb_ok = true;
     for (int i = 0; i < 3; ++i) {
       const ConvArgs& a = g.c[i];
@@ -645,7 +645,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GATE16"); return e && std::atoi(e) != 0; }();
   // more 32-row tiles than this and the launch fills the chip either way (measured: profiles/NOTES.md)
   static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_GATE16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
-  if (off || !ctx->gate16.load() || !c.g16_J || n_max <= 0) return 1;
+  if (off || !w->o_gate16 || !c.g16_J || n_max <= 0) return 1;
   const int PA = (a.pad + 3) & ~3;
   if ((PA - a.pad) + 31 + (c.K - 1) * a.dil >= GATE16_XW || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
   const int gx = (n_max + 31) / 32, gy = (a.half + 7) / 8;
@@ -697,7 +697,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   // more tiles than this and the chunked 32-row tile fills the chip (longer rows, bigger batches)
   static const long long max_tiles = [] { const char* e = std::getenv("MI355TTS_LIN16_MAX_TILES"); return e ? std::atoll(e) : 1LL << 40; }();
   static const bool no_k1 = [] { const char* e = std::getenv("MI355TTS_LIN16_NO_K1"); return e && std::atoi(e) != 0; }();
-  if (off || !ctx->glow_fuse.load() || !c.l16_J || n_max <= 0 || (c.K == 1 && no_k1)) return 1;
+  if (off || !w->o_glow_fuse || !c.l16_J || n_max <= 0 || (c.K == 1 && no_k1)) return 1;
   const int PA = (a.pad + 3) & ~3;
   if ((PA - a.pad) + (c.K - 1) * a.dil > 16 || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
   if (a.x2 || a.alpha != 1.0f || a.accum || a.in_slope != 1.0f || (a.out_act != ACT_NONE && a.out_act != ACT_RELU)) return 1;

@@ -199,6 +199,20 @@ struct GlowBlock {
 };
 // Models are handed out as shared_ptr pins: a call keeps its models alive for its whole duration, mi355tts_unload only
 // drops the context's reference, and the device memory goes when the last call that uses the model has returned.
+// RAII: make `device` current for a scope, then put the caller's device back (a destructor that runs on whichever thread
+// drops the last reference must not change that thread's current device)
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) hipSetDevice(device);
+    else prev = -1;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) hipSetDevice(prev);
+  }
+};
+
 struct GlowModel {
   mi355tts_glow_hparams hp;
   int device = 0;
@@ -206,7 +220,7 @@ struct GlowModel {
   std::atomic<int> precision{0};  // the `half` switch (see HifiModel::precision)
   ~GlowModel() {
     if (arena) {
-      hipSetDevice(device);
+      DeviceScope ds(device);
       hipFree(arena);
     }
   }
@@ -251,7 +265,7 @@ struct HifiModel {
   float* bias_spec = nullptr;
   bool bias_ready = false;
   ~HifiModel() {
-    hipSetDevice(device);
+    DeviceScope ds(device);
     if (arena) hipFree(arena);
     if (arena16) hipFree(arena16);
     if (bias_spec) hipFree(bias_spec);

@@ -156,7 +156,8 @@ class Engine:
         """`ids`: one int64 vector [P] or a list of them (variable length batch).
         `noise`: optional [B, M, >=F] (or [M, >=F] for B=1) standing in for the
         reference's `torch.randn_like` draw.  Without it the device generator draws: row b from
-        the stream `row_seeds[b]` (default `seed + b`) — the field a batch-1 call with that seed draws."""
+        the stream `row_seeds[b]` (default `seed + b`: successive BATCHED calls must advance `seed` by the batch size)
+        — the field a batch-1 call with that seed draws."""
         rows = [np.asarray(ids, np.int64)] if isinstance(ids, np.ndarray) and ids.ndim == 1 else [np.asarray(r, np.int64) for r in ids]
         if isinstance(ids, np.ndarray) and ids.ndim == 2:
             rows = [np.asarray(r, np.int64) for r in ids]

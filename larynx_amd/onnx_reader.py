@@ -70,7 +70,13 @@ def _signed(x: int) -> int:
     return x - (1 << 64) if x >= 1 << 63 else x
 
 
-def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
+class Unreadable(str):
+    """Why an initializer could not be read (external data, element-count mismatch, unknown type).  Only tensors the
+    weight loader actually NEEDS turn this into an error (`onnx_weights.state_dict_from_onnx`): a voice file may carry an
+    unrelated tensor this reader cannot take."""
+
+
+def _tensor(buf, strict: bool = True) -> typing.Tuple[str, typing.Union[np.ndarray, Unreadable]]:
     b = bytes(buf)
     dims: typing.List[int] = []
     dtype, name, raw = 1, "", None
@@ -97,11 +103,16 @@ def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
             external = True
         elif f == 14:  # data_location: 1 = EXTERNAL
             external = external or v == 1
+    def bad(msg):
+        if strict:
+            raise ValueError(msg)
+        return name, Unreadable(msg)
+
     if dtype not in _DTYPES:
-        raise ValueError(f"tensor '{name}': unsupported ONNX data type {dtype}")
+        return bad(f"tensor '{name}': unsupported ONNX data type {dtype}")
     if external and raw is None:
-        raise ValueError(f"tensor '{name}': its data lives in an external file (data_location = EXTERNAL), which this reader "
-                         "does not follow — re-export the model with the weights embedded")
+        return bad(f"tensor '{name}': its data lives in an external file (data_location = EXTERNAL), which this reader "
+                   "does not follow — re-export the model with the weights embedded")
     if dtype == 10 and raw is None and ints:
         # float16 values in int32_data are BIT PATTERNS (onnx.proto: "float16 values must be bit-wise converted to an uint16_t")
         raw = np.asarray(ints, np.uint16).tobytes()
@@ -117,7 +128,7 @@ def _tensor(buf) -> typing.Tuple[str, np.ndarray]:
     shape = tuple(int(d) for d in dims)
     want = int(np.prod(shape, dtype=np.int64))
     if arr.size != want:
-        raise ValueError(f"tensor '{name}': {arr.size} elements stored for dims {list(shape)} ({want} expected)")
+        return bad(f"tensor '{name}': {arr.size} elements stored for dims {list(shape)} ({want} expected)")
     return name, arr.reshape(shape)
 
 
@@ -169,6 +180,7 @@ class OnnxGraph(typing.NamedTuple):
     initializers: typing.Dict[str, np.ndarray]     # name -> tensor, incl. the value of every Constant node
     inputs: typing.List[str]
     outputs: typing.List[str]
+    unreadable: typing.Dict[str, str] = {}         # initializer name -> why it could not be read (see `Unreadable`)
 
 
 def read_onnx(path: typing.Union[str, Path]) -> OnnxGraph:
@@ -181,6 +193,7 @@ def read_onnx(path: typing.Union[str, Path]) -> OnnxGraph:
         raise ValueError(f"{path}: not an ONNX ModelProto (no graph)")
     nodes: typing.List[Node] = []
     inits: typing.Dict[str, np.ndarray] = {}
+    bad: typing.Dict[str, str] = {}
     inputs: typing.List[str] = []
     outputs: typing.List[str] = []
 
@@ -194,8 +207,11 @@ def read_onnx(path: typing.Union[str, Path]) -> OnnxGraph:
         if f == 1:
             nodes.append(_node(v))
         elif f == 5:
-            name, arr = _tensor(v)
-            inits[name] = arr
+            name, arr = _tensor(v, strict=False)
+            if isinstance(arr, Unreadable):
+                bad[name] = str(arr)
+            else:
+                inits[name] = arr
         elif f == 11:
             inputs.append(value_name(v))
         elif f == 12:
@@ -203,4 +219,4 @@ def read_onnx(path: typing.Union[str, Path]) -> OnnxGraph:
     for n in nodes:  # Constant nodes carry tensors the exporter did not hoist into initializers
         if n.op_type == "Constant" and "value" in n.attrs and isinstance(n.attrs["value"], np.ndarray) and n.outputs:
             inits.setdefault(n.outputs[0], n.attrs["value"])
-    return OnnxGraph(nodes, inits, [i for i in inputs if i not in inits], outputs)
+    return OnnxGraph(nodes, inits, [i for i in inputs if i not in inits], outputs, bad)

@@ -184,6 +184,10 @@ def state_dict_from_onnx(path: typing.Union[str, Path], manifest_names: typing.S
     need_anb = [m for m in missing if m.endswith(".bias") and m[: -len(".bias")] + ".logs" in need_logs]
     other = [m for m in missing if m not in need_inv + need_gamma + need_beta + need_logs + need_anb]
     if other:
+        # a needed tensor the reader saw but could not take (external data, element-count mismatch): say THAT
+        why = [msg for raw, msg in G.g.unreadable.items() if any(_strip_prefix(raw) in (o, o[:-7] + ".weight_g", o[:-7] + ".weight_v") for o in other)]
+        if why:
+            raise ValueError(f"{path}: {why[0]}")
         raise KeyError(f"{path}: no tensor for {other[:4]}{' ...' if len(other) > 4 else ''} (exporter layout not recognised)")
     if need_inv:
         # the manifest lists blocks 0..n-1; the reverse pass executes n-1..0

@@ -83,8 +83,10 @@ def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[n
     """This rank's share of the work list -> {utterance index: int16 audio}.
     `batch` > 1 runs length-bucketed micro-batches through one pair of calls each.  The
     kernels mask by row length and the device RNG stream of a row is keyed by the UTTERANCE
-    (`seed + utterance index`, `mi355tts_glow_infer_rows`), so every utterance gets the audio a
-    call of its own would give it — whatever rank it lands on and whatever batch it rides in."""
+    (`seed + utterance index`, `mi355tts_glow_infer_rows`), so every utterance draws the noise
+    field a call of its own would draw, whatever rank it lands on and whatever batch it rides
+    in.  The audio is then equal to the single call's UP TO f32 SUMMATION ORDER (a padded batch
+    picks other tile shapes than a batch-1 launch: +-1 int16 LSB in the tests), not bit for bit."""
     lengths = [len(r) for r in id_rows]
     mine = lpt_assign(lengths, world)[rank]
     out: typing.Dict[int, np.ndarray] = {}

@@ -119,3 +119,46 @@ def test_exporter_variants_from_the_reference_modules(emu_library_path, tmp_path
     assert p.returncode == 0, p.stderr[-3000:]
     worst = json.loads(p.stdout.strip().splitlines()[-1])
     assert worst["hifigan"] < 2e-6 and worst["glow"] < 2e-6, worst
+
+
+def _varint(n: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _with_extra_initializer(src, dst, tensor: bytes):
+    """Copy an ONNX file, appending one TensorProto to graph.initializer (ModelProto field 7 -> GraphProto field 5)."""
+    from larynx_amd.onnx_reader import _fields
+
+    out = bytearray()
+    for f, w, v in _fields(src.read_bytes()):
+        if f == 7 and w == 2:
+            v = bytes(v) + b"\x2a" + _varint(len(tensor)) + tensor
+        if w == 2:
+            out += _varint((f << 3) | 2) + _varint(len(v)) + bytes(v)
+        elif w == 0:
+            out += _varint((f << 3) | 0) + _varint(v)
+        else:
+            raise AssertionError("unexpected wire type in a ModelProto")
+    dst.write_bytes(bytes(out))
+
+
+def test_an_unrelated_unreadable_initializer_does_not_block_a_voice(tmp_path):
+    """A file may carry a tensor this reader cannot take (data in an external file, odd element count).  Only tensors the
+    weight loader needs turn that into an error — and then the error says why."""
+    name = b"extra.lookup_table"
+    ext = b"\x08\x02" + b"\x10\x01" + b"\x42" + _varint(len(name)) + name + b"\x70\x01"  # dims [2], FLOAT, name, data_location = EXTERNAL
+    f = tmp_path / "generator.onnx"
+    _with_extra_initializer(FIX / "hifigan" / "generator.onnx", f, ext)
+    g = read_onnx(f)
+    assert "extra.lookup_table" in g.unreadable and "extra.lookup_table" not in g.initializers
+    ref = state_dict_from_onnx(FIX / "hifigan" / "generator.onnx", ["conv_pre.weight", "conv_pre.bias"])
+    got = state_dict_from_onnx(f, ["conv_pre.weight", "conv_pre.bias"])
+    assert sorted(got) == sorted(ref) and all(np.array_equal(got[k], ref[k]) for k in ref)
+    with pytest.raises(ValueError, match="external file"):
+        state_dict_from_onnx(f, ["conv_pre.weight", "extra.lookup_table"])

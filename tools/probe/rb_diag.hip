@@ -266,6 +266,39 @@ int main(int argc, char** argv) {
     const double us = 1e3 * ms / N;
     printf("L x%d wgs=%d: %.1f us/launch  %.1f TFLOP/s (%.3f of 157.3)\n", mul, g.off[3], us, flop / us / 1e6, flop / us / 1e6 / 157.3);
   }
+  // ---- 1b. pipeline conditions: every member on its OWN planes (as the three MRF chains are), six launches chained
+  // x -> t -> x' ... (the input of a launch is what the previous launch wrote), a different weight set per launch
+  {
+    const int NW = 6, L = CG_L;
+    std::vector<ConvGroupArgs> gs(NW);
+    float* pl[3][2];
+    for (int m = 0; m < 3; ++m)
+      for (int q = 0; q < 2; ++q) { CK(hipMalloc(&pl[m][q], (size_t)C * L * 4)); CK(hipMemcpy(pl[m][q], dx, (size_t)C * L * 4, hipMemcpyDeviceToDevice)); }
+    double flop = 0;
+    for (int i = 0; i < NW; ++i) {
+      make(L, 0, gs[i], flop);
+      for (int m = 0; m < 3; ++m) {
+        ConvArgs& a = gs[i].c[m];
+        float* dwi; const size_t wn = (size_t)(C / 32) * noct[m] * Ks[m] * 256;
+        CK(hipMalloc(&dwi, wn * 4)); CK(hipMemcpy(dwi, dw[m], wn * 4, hipMemcpyDeviceToDevice));
+        a.w = dwi; a.x = pl[m][i & 1]; a.y = pl[m][(i & 1) ^ 1]; a.res = (i & 1) ? pl[m][(i & 1) ^ 1] : nullptr;
+        if (i & 1) a.res = nullptr;  // (in place: conv2 adds x = the plane it overwrites; timing only — keep the values bounded instead)
+        a.bias = db[m];
+      }
+    }
+    for (int r = 0; r < 3; ++r) for (int i = 0; i < NW; ++i) launch(gs[i], st[0], 0);
+    CK(hipStreamSynchronize(st[0]));
+    for (int m = 0; m < 3; ++m)
+      for (int q = 0; q < 2; ++q) CK(hipMemcpy(pl[m][q], dx, (size_t)C * L * 4, hipMemcpyDeviceToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int N = 2;
+    CK(hipEventRecord(e0, st[0]));
+    for (int r = 0; r < N; ++r) for (int i = 0; i < NW; ++i) launch(gs[i], st[0], 0);
+    CK(hipEventRecord(e1, st[0])); CK(hipStreamSynchronize(st[0]));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / (N * NW);
+    printf("chained, own planes, rotating weights: %.1f us/launch  %.1f TFLOP/s (%.3f of 157.3)\n", us, flop / us / 1e6, flop / us / 1e6 / 157.3);
+  }
   // ---- 2. S streams, each launching the L-column problem N times
   for (int S = 1; S <= NSTREAM; S *= 2) {
     ConvGroupArgs g[NSTREAM]; double flop = 0;
