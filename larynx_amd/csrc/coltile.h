@@ -24,6 +24,7 @@
 // of the twelve row tiles of H = 192.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "prio.h"
 #include <type_traits>
 
 namespace mi355tts {
@@ -215,6 +216,7 @@ struct GlowTailArgs {
 };
 
 __global__ __launch_bounds__(512) void glow_tail_kernel(const GlowTailArgs a) {
+  GLOW_PRIO();
   // R1: acts, then m|logs;  R2: skip -> s, then the new z0;  R3: z
   __shared__ float lds[3 * COL_MAXROWS * COL_T];
   float* R1 = lds;
@@ -378,6 +380,7 @@ struct OprojLnArgs {
 };
 
 __global__ __launch_bounds__(512) void oproj_ln_kernel(const OprojLnArgs a) {
+  GLOW_PRIO();
   __shared__ float lds[2 * COL_MAXROWS * COL_T];
   __shared__ float red[32][COL_T + 1];
   float* R1 = lds;

@@ -19,6 +19,7 @@
 // (glow_tts/layers.py:73-80,138-162; attentions.py:119-142,375-383).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "prio.h"
 
 // Micro-benchmark ablations (tools/conv_probe.py) are compiled in only for probe builds
 // (-DMI355TTS_ABLATION): a runtime test around the weight loads puts them behind a branch,
@@ -44,6 +45,7 @@
 #endif
 
 namespace mi355tts {
+
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 

@@ -18,6 +18,7 @@
 // GlowTTS (FFN, duration predictor, prenet, 1 x 1 convs), optionally with the producer's LayerNorm as a prologue.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "prio.h"
 
 namespace mi355tts {
 
@@ -27,7 +28,16 @@ namespace mi355tts {
 
 typedef float gate_floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int GATE16_XW = 48;       // staged columns per channel row (32 + up to 16 of halo and alignment)
+// Staged halo + alignment columns per channel row.  16 made the row stride 48 = 16 mod 32 (conflict-free fragment reads) but the
+// tile of a 192-channel conv 36 KB — one LDS page MORE than the 32 KB hole a finishing ResBlock workgroup (rb_conv.h) leaves
+// on a loaded CU: under load such a launch waited for TWO holes on one CU (measured: a 240-workgroup launch of 60 KB
+// workgroups takes ~19 us next to four streams of ResBlock launches, of 30 KB workgroups ~8 us; tools/probe/rb_diag.hip).  8 is
+// enough for every k <= 5, d = 1 conv of GlowTTS (30 KB; two-way bank conflicts on half of a fragment read's lanes, in
+// kernels whose LDS pipe is idle 90 % of the time); wider taps / dilations take the generic tile (host check).
+#ifndef MI355TTS_G16_HALO
+#define MI355TTS_G16_HALO 8
+#endif
+constexpr int GATE16_XW = 32 + MI355TTS_G16_HALO;  // staged columns per channel row
 constexpr int GATE16_MAX_CIN = 512;  // 96 KB of LDS
 
 struct Gate16Args {
@@ -48,6 +58,7 @@ struct Gate16Args {
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J)
 template <int K, int J>
 __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
+  GLOW_PRIO();
   __shared__ float xs[(32 * J * GATE16_XW > 4096) ? 32 * J * GATE16_XW : 4096];  // [32 J][48]; afterwards the partial tiles [8][2][4][64]
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
   const int b = blockIdx.z;
@@ -194,8 +205,9 @@ struct Lin16Args {
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J), NBLK = 16-column blocks per workgroup (1 or 2)
 template <int K, int J, int NBLK, bool LN = false>
 __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
+  GLOW_PRIO();
   constexpr int TC = 16 * NBLK;  // columns per workgroup
-  constexpr int XW = TC + 16;    // staged columns per channel row
+  constexpr int XW = TC + MI355TTS_G16_HALO;  // staged columns per channel row
   __shared__ float xs[(32 * J * XW > 2048 * NBLK) ? 32 * J * XW : 2048 * NBLK];  // [32 J][XW]; afterwards the partial tiles [8][NBLK][4][64]
   __shared__ float lnred[LN ? 8 * 64 : 1];
   static_assert(!LN || XW <= 64, "LayerNorm prologue: one lane per staged column");

@@ -305,9 +305,15 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       ProfScope ps(ctx, w, KC_SMALL, 0);
       const dim3 ag((Pmax + 31) / 32, nh, B);
       const int dkh = H / nh;
-#define ATT_LAUNCH_X(NK, X)                                                                                              \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK, X>), ag, dim3(512), 0, s, qkv, 3 * bsH, P, d_len, H, nh,  \
+      static const bool att_big = [] { const char* e = std::getenv("MI355TTS_ATT_BIG_LDS"); return e && std::atoi(e) != 0; }();  // (A/B runs)
+#define ATT_LAUNCH_P(NK, X, PM)                                                                                             \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(attention_mfma_kernel<NK, X, PM>), ag, dim3(512), 0, s, qkv, 3 * bsH, P, d_len, H, nh, \
                      h.window_size, A + L.ek, A + L.ev, t2, bsH, P)
+#define ATT_LAUNCH_X(NK, X)                        \
+  do {                                             \
+    if (Pmax <= 256 && !att_big) ATT_LAUNCH_P(NK, X, 256); \
+    else ATT_LAUNCH_P(NK, X, ATTM_MAXP);           \
+  } while (0)
 #define ATT_LAUNCH(NK)                                                                                                   \
   do {                                                                                                                   \
     if (dkh == 2 * NK) ATT_LAUNCH_X(NK, true);                                                                           \
@@ -319,6 +325,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       else if (Pmax <= ATTM_MAXP) ATT_LAUNCH(64);
 #undef ATT_LAUNCH
 #undef ATT_LAUNCH_X
+#undef ATT_LAUNCH_P
       else
         hipLaunchKernelGGL(attention_kernel, dim3(att_rows / ATT_ROWS, nh, B), dim3(256), 0, s, qkv, 3 * bsH, P, d_len, H, nh,
                            h.window_size, A + L.ek, A + L.ev, t2, bsH, P, sc, P);
@@ -396,7 +403,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     hipStream_t st;
     ~MelGuard() {
       if (!m) return;
-      hipStreamSynchronize(st);
+      mi355_sync(st);
       mel_destroy(m);
     }
   } mguard{mel, s};
@@ -407,7 +414,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   }
   if ((size_t)B > w->pinned_ints) return fail(MI355TTS_ERR_INVALID, "batch too large");
   HIPCHECK(hipMemcpyAsync(w->pinned, mel->frames_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(mi355_sync(s));
   int Fmax = 0;
   for (int b = 0; b < B; ++b) {
     mel->frames[b] = w->pinned[b];
@@ -552,7 +559,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
                        nsq, mel->raw, mel->voc, (long long)M * Fld, Fld, to_mt(audio), audio ? 1 : 0);
   }
   if (final_sync) {
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(mi355_sync(s));
     HIPCHECK(hipGetLastError());
   }
   mguard.m = nullptr;

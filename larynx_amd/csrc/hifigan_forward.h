@@ -36,7 +36,7 @@ static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
       WorkerGuard guard{ctx, w};
       hipLaunchKernelGGL(stft_denoise_kernel, dim3(1, 1), dim3(256), 0, w->stream, dwav, (long long)N, zm->frames_dev, hop,
                          (const float*)nullptr, 0.f, (float*)nullptr, 1, bias);
-      if (hipStreamSynchronize(w->stream) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "denoiser bias kernel failed");
+      if (mi355_sync(w->stream) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "denoiser bias kernel failed");
     }
   }
   mel_destroy(zm);
@@ -141,7 +141,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     if (out_dev) {
       if (wav_f32) HIPCHECK(hipMemsetAsync(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld, s));
       if (wav_i16) HIPCHECK(hipMemsetAsync(wav_i16, 0, sizeof(int16_t) * (size_t)B * wav_ld, s));
-      HIPCHECK(hipStreamSynchronize(s));
+      HIPCHECK(mi355_sync(s));
     } else {
       if (wav_f32) std::memset(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld);
       if (wav_i16) std::memset(wav_i16, 0, sizeof(int16_t) * (size_t)B * wav_ld);
@@ -155,9 +155,9 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     bool ok = false;
     ~DrainOnError() {
       if (ok) return;
-      hipStreamSynchronize(w->stream);
+      mi355_sync(w->stream);
       for (int i = 0; i < 2; ++i)
-        if (w->aux[i]) hipStreamSynchronize(w->aux[i]);
+        if (w->aux[i]) mi355_sync(w->aux[i]);
     }
   } drain{w};
   const int C0 = h.upsample_initial_channel;
@@ -467,7 +467,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
         if (wav_ld > rowlen) HIPCHECK(hipMemsetAsync(dst + rowlen, 0, sizeof(short) * (size_t)(wav_ld - rowlen), s));
       }
     }
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(mi355_sync(s));
     HIPCHECK(hipGetLastError());
     drain.ok = true;
     return 0;
@@ -483,7 +483,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     if (wav_f32) HIPCHECK(hipMemcpyAsync(pf + (size_t)b * N, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, s));
     if (wav_i16) HIPCHECK(hipMemcpyAsync(pi + (size_t)b * rowlen, i16 + (size_t)b * ild, sizeof(short) * (size_t)rowlen, hipMemcpyDeviceToHost, s));
   }
-  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(mi355_sync(s));
   HIPCHECK(hipGetLastError());
   drain.ok = true;
   for (int b = 0; b < B; ++b) {

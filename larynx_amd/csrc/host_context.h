@@ -14,6 +14,28 @@ static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_
                                             "conv_mfma.glow_decoder",     "elementwise",
                                             "mrf_small.hifigan_narrow_stage"};
 
+// Host wait for a stream.  hipStreamSynchronize SPINS (a caller thread burns a core while its ~4 ms of kernels run, and 8 of
+// them contend with the launching threads for the runtime's locks); MI355TTS_SYNC_MODE=1 waits on a blocking event
+// (interrupt), =2 polls hipStreamQuery with a short sleep.  Read once.
+static hipError_t mi355_sync(hipStream_t s) {
+  static const int mode = [] { const char* e = std::getenv("MI355TTS_SYNC_MODE"); return e ? std::atoi(e) : 0; }();
+  if (mode == 1) {
+    thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return hipStreamSynchronize(s);
+    hipError_t e = hipEventRecord(ev, s);
+    return e == hipSuccess ? hipEventSynchronize(ev) : e;
+  }
+  if (mode == 2) {
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  return hipStreamSynchronize(s);
+}
+
 struct Worker {
   hipStream_t stream = nullptr;
   char* arena = nullptr;
@@ -34,6 +56,10 @@ struct Worker {
   // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
   // a mi355tts_set_option from another thread never changes a call's schedule half way through)
   bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true;
+  // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
+  // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_glow = nullptr;
 };
 
 struct mi355tts_ctx {
@@ -60,6 +86,10 @@ struct mi355tts_ctx {
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
+  // mi355tts_synthesize: GlowTTS on a high-priority stream of the call's worker (see Worker::gstream).  The hardware queues
+  // run one kernel at a time each and the runtime maps all bulk streams onto 4 of them: a call's chain of ~140 small
+  // dependent launches otherwise advances one launch per 200 us ResBlock kernel of the stream it shares a queue with
+  std::atomic<int> glow_priority{0};
   // concurrent batch-1 mi355tts_synthesize calls share ONE GlowTTS pass (host_join.h): the callers waiting when a pass
   // starts become its rows.  Off by default: measured neutral to -1 % on the 'high' vocoder (profiles/NOTES.md)
   std::atomic<bool> glow_coalesce{false};

@@ -64,6 +64,8 @@ template <> struct ConvCfg<11> { static constexpr int HALO = 56; };
 enum TileShape { TILE_SMALL = 0, TILE_W128 = 1, TILE_NB2 = 2, TILE_TINY = 3, TILE_LAST = 3, TILE_M128 = 4 };
 static thread_local int g_pin_tile = -1;  // set by mi355tts_bench_conv1d only
 
+// option "rb_conv" as the running call saw it (set by run_plan from the worker's snapshot: launch_conv_k has no worker)
+static thread_local bool g_rb_conv_on = true;
 template <int K, int EPI>
 static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvArgs& a) {
   constexpr int HALO = ConvCfg<K>::HALO;
@@ -81,6 +83,15 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   }
   if constexpr (EPI == EPI_UPSAMPLE) {
     if (shape == TILE_M128) {  // the polyphase upsampler's virtual rows, 128 per workgroup from one staged input tile
+      if constexpr (K == 2) {
+        // the continuous-stream tile (rb_conv.h; same bits): taps 2 — every upsampler of the shipped vocoders (k_u = 2 u)
+        static const bool rb_off = [] { const char* e = std::getenv("MI355TTS_NO_RB_CONV"); return e && std::atoi(e) != 0; }();
+        if (!rb_off && g_rb_conv_on && a.Cin % 16 == 0 && !a.res && !a.accum && a.alpha == 1.0f) {
+          if (a.x2 && a.x3) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<2, 4, EPI_UPSAMPLE, true>), grid, dim3(256), 0, s, a);
+          else if (!a.x2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<2, 4, EPI_UPSAMPLE, false>), grid, dim3(256), 0, s, a);
+          if ((a.x2 && a.x3) || !a.x2) return 0;
+        }
+      }
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 1, 1, HALO, EPI, 4>), grid, dim3(256), 0, s, a);
       return 0;
     }
@@ -277,6 +288,7 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   const int MB = p.MB, shape = p.shape;
   const dim3 grid = p.grid;
   int rc = 0;
+  g_rb_conv_on = w->o_rb_conv;
   if (p.bf16) {
 #define BF16_LAUNCH_T(KK, TT)                                                                                                      \
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a);      \
@@ -699,7 +711,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   static const bool no_k1 = [] { const char* e = std::getenv("MI355TTS_LIN16_NO_K1"); return e && std::atoi(e) != 0; }();
   if (off || !w->o_glow_fuse || !c.l16_J || n_max <= 0 || (c.K == 1 && no_k1)) return 1;
   const int PA = (a.pad + 3) & ~3;
-  if ((PA - a.pad) + (c.K - 1) * a.dil > 16 || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
+  if ((PA - a.pad) + (c.K - 1) * a.dil > MI355TTS_G16_HALO || a.x_ld % 4 || a.in_mul != a.out_mul || a.in_len != a.out_len) return 1;
   if (a.x2 || a.alpha != 1.0f || a.accum || a.in_slope != 1.0f || (a.out_act != ACT_NONE && a.out_act != ACT_RELU)) return 1;
   const bool two = a.split < c.rows;  // second output for the rows >= split
   if (two && (!a.y2 || a.split < 0 || a.split % 16)) return 1;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <time.h>
 #include <atomic>
 #include <condition_variable>
 #include <cmath>
@@ -75,6 +76,8 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
       if (w->ev_join[i]) hipEventDestroy(w->ev_join[i]);
     }
     if (w->ev_fork) hipEventDestroy(w->ev_fork);
+    if (w->gstream) hipStreamDestroy(w->gstream);
+    if (w->ev_glow) hipEventDestroy(w->ev_glow);
     if (w->arena) hipFree(w->arena);
     if (w->pinned) hipHostFree(w->pinned);
     if (w->pinned_out) hipHostFree(w->pinned_out);
@@ -596,7 +599,7 @@ extern "C" int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, in
   WorkerGuard guard{ctx, w};
   const int rc = bcast(device_blob, device_blob, (size_t)numel, /*ncclFloat32*/ 7, root, nccl_comm, w->stream);
   if (rc != 0) return fail(MI355TTS_ERR_HIP, "ncclBroadcast failed: %s", errstr ? errstr(rc) : "?");
-  HIPCHECK(hipStreamSynchronize(w->stream));
+  HIPCHECK(mi355_sync(w->stream));
   return 0;
 }
 
@@ -742,7 +745,7 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
       e = hipMemcpyAsync(m->voc, m->raw, n * sizeof(float), hipMemcpyDeviceToDevice, w->stream);
     }
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  if (e == hipSuccess) e = mi355_sync(w->stream);
   if (e != hipSuccess) {
     mel_destroy(m);
     return fail(MI355TTS_ERR_HIP, "mel_from_buffer: %s", hipGetErrorString(e));
@@ -819,7 +822,7 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
       Worker* w;
       std::shared_ptr<GlowBatch>* b;
       ~BatchDrop() {
-        hipStreamSynchronize(w->stream);  // the row's blocks go back to the pool with the last caller: nothing of ours may still read them
+        mi355_sync(w->stream);  // the row's blocks go back to the pool with the last caller: nothing of ours may still read them
         b->reset();
       }
     } drop{w, &req.batch};
@@ -829,12 +832,32 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
     return hifigan_run(ctx, w, hm, &view, v);
   }
   mi355tts_mel* mel = nullptr;
-  CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
+  const int gprio = ctx->glow_priority.load();
+  if (gprio) {
+    if (!w->gstream) {
+      int least = 0, greatest = 0;
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIPCHECK(hipStreamCreateWithPriority(&w->gstream, hipStreamNonBlocking, gprio == 2 ? least : greatest));
+      HIPCHECK(hipEventCreateWithFlags(&w->ev_glow, hipEventDisableTiming));
+    }
+    hipStream_t bulk = w->stream;
+    w->stream = w->gstream;  // the worker belongs to this call: everything glow_run queues goes to the priority stream
+    const int rc = glow_run(ctx, w, gm, g, Pmax, false, &mel);
+    w->stream = bulk;
+    if (rc != 0) {
+      mi355_sync(w->gstream);
+      return rc;
+    }
+    HIPCHECK(hipEventRecord(w->ev_glow, w->gstream));
+    HIPCHECK(hipStreamWaitEvent(bulk, w->ev_glow, 0));
+  } else {
+    CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
+  }
   struct MelDrop {
     Worker* w;
     mi355tts_mel* m;
     ~MelDrop() {
-      hipStreamSynchronize(w->stream);  // its blocks go back to the pool: nothing queued may still read them
+      mi355_sync(w->stream);  // its blocks go back to the pool: nothing queued may still read them
       mel_destroy(m);
     }
   } drop{w, mel};
@@ -985,7 +1008,7 @@ static int op_conv_common(mi355tts_ctx* ctx, const float* x, int B, int Cin, int
   }
   if (rc) return rc;
   HIPCHECK(hipMemcpyAsync(y, dy, sizeof(float) * (size_t)B * Cout * Lout, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(mi355_sync(s));
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -1031,7 +1054,7 @@ extern "C" int mi355tts_op_denoise(mi355tts_ctx* ctx, const float* wav, int B, i
                      (float*)nullptr);
   hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fb, T, dfr, DN_HOP, dout, (long long)N, (long long)N);
   HIPCHECK(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)B * N, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(mi355_sync(s));
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -1047,7 +1070,7 @@ extern "C" int mi355tts_op_gauss_noise(mi355tts_ctx* ctx, uint64_t seed, int B, 
   float* d = (float*)w->arena;
   hipLaunchKernelGGL(noise_fill_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, w->stream, d, C, T, seed);
   HIPCHECK(hipMemcpyAsync(out, d, n * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-  HIPCHECK(hipStreamSynchronize(w->stream));
+  HIPCHECK(mi355_sync(w->stream));
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -1102,7 +1125,7 @@ extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout
     hipEventRecord(e0, s);
     for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(ctx, w, c, a, EPI_LINEAR, B, L, KC_RESBLOCK);
     hipEventRecord(e1, s);
-    hipError_t e = hipStreamSynchronize(s);
+    hipError_t e = mi355_sync(s);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     if (e != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "bench_conv1d: %s", hipGetErrorString(e));
@@ -1151,6 +1174,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "rb_conv") == 0) {
     ctx->rb_conv = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "glow_priority") == 0) {
+    ctx->glow_priority = value;
     return 0;
   }
   if (std::strcmp(name, "serial_branches") == 0) {

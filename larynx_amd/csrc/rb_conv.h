@@ -37,9 +37,13 @@ template <int HALO>
 constexpr int rb_lds_floats() { return 4 * rb_buf_floats<HALO>(); }
 
 // One workgroup (4 waves = 4 row groups of 32 rows) = rows [128 tile_y, +128) x columns [64 tile_x, +64) of batch row b.
-// Supported ConvArgs: x (no x2 / x3), bias, res, y; alpha = 1, no accumulate / activation / row split (the host checks).
-template <int K, int HALO>
+// EPI_LINEAR: ConvArgs x (no x2 / x3), bias, res, y; alpha = 1, no accumulate / activation / row split (the host checks).
+// EPI_UPSAMPLE: the polyphase ConvTranspose1d of conv_tile (K = 2 taps, rows = C_out * u virtual rows scattered to
+// q u + r - pad), optionally with MRF = the consumer-side MRF average: input = ((x + x2) + x3) / in_div, summed when the
+// tile is written to LDS — the three planes' loads go out together a chunk earlier, nothing waits for them.
+template <int K, int HALO, int EPI = EPI_LINEAR, bool MRF = false>
 __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "rb_tile: linear and upsample epilogues");
   constexpr int CI_C = 16, NB = 2, NT = 256, T_T = 64;
   constexpr int XW = T_T + HALO, XW4 = XW / 4, OCTS = CI_C / 8, S = OCTS * K;
   constexpr int NF4 = CI_C * XW4, NE = (NF4 + NT - 1) / NT;
@@ -52,7 +56,8 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
   const int mt0 = tile_y * 4 + wm;
   const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
   const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
-  if (t0 >= Lout) return;  // uniform per workgroup
+  const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;  // extent of the GEMM's N axis
+  if (t0 >= n_len) return;  // uniform per workgroup
 
   const float slope = a.in_slope;
   const float* xb = a.x + (long long)b * a.x_bs;
@@ -62,7 +67,10 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
   const int cin_last = a.Cin - 1, ld_last4 = a.x_ld - 4;
 
   // staging: as conv_tile (16-byte loads from clamped addresses, mask + leaky-ReLU on the way into LDS), one register set
-  float4 pre[NE];
+  constexpr int NP = MRF ? 3 : 1;  // input planes
+  const float* xb2 = MRF ? a.x2 + (long long)b * a.x_bs : nullptr;
+  const float* xb3 = MRF ? a.x3 + (long long)b * a.x_bs : nullptr;
+  float4 pre[NE * NP];
   auto gload = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -70,7 +78,12 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
       const int row = e / XW4, f = e - row * XW4;
       const int ci = chunk * CI_C + (row < CI_C ? row : CI_C - 1);
       const int c0 = t0 - PA + 4 * f;
-      pre[i] = *reinterpret_cast<const float4*>(xb + (ci < a.Cin ? ci : cin_last) * a.x_ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0)));
+      const int off = (ci < a.Cin ? ci : cin_last) * a.x_ld + (c0 < 0 ? 0 : (c0 > ld_last4 ? ld_last4 : c0));
+      pre[i] = *reinterpret_cast<const float4*>(xb + off);
+      if constexpr (MRF) {
+        pre[NE + i] = *reinterpret_cast<const float4*>(xb2 + off);
+        pre[2 * NE + i] = *reinterpret_cast<const float4*>(xb3 + off);
+      }
     }
   };
   auto lstore1 = [&](int buf, int chunk, int i) {
@@ -79,6 +92,13 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
     const int c0 = t0 - PA + 4 * f;
     const bool fok = chunk * CI_C + row < a.Cin && f < used4;
     float4 v = pre[i];
+    if constexpr (MRF) {  // xs / num_kernels of hifi_gan/models.py:191-197, in conv_tile's order: ((x + x2) + x3) / in_div
+      const float4 v2 = pre[NE + i], v3 = pre[2 * NE + i];
+      v.x = ((v.x + v2.x) + v3.x) / a.in_div;
+      v.y = ((v.y + v2.y) + v3.y) / a.in_div;
+      v.z = ((v.z + v2.z) + v3.z) / a.in_div;
+      v.w = ((v.w + v2.w) + v3.w) / a.in_div;
+    }
     v.x = (fok && c0 >= 0 && c0 < Lin) ? v.x : 0.f;
     v.y = (fok && c0 + 1 >= 0 && c0 + 1 < Lin) ? v.y : 0.f;
     v.z = (fok && c0 + 2 >= 0 && c0 + 2 < Lin) ? v.z : 0.f;
@@ -117,25 +137,26 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
 #pragma unroll
   for (int i = 0; i < RD - 1; ++i) ar[i] = wq[a_index(0, i)];
   {
-    float4 p0[NE];
+    constexpr int NR = NE * NP;
+    float4 p0[NR];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) p0[i] = pre[i];
+    for (int i = 0; i < NR; ++i) p0[i] = pre[i];
     gload(1);
-    float4 p1[NE];
+    float4 p1[NR];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) p1[i] = pre[i];
+    for (int i = 0; i < NR; ++i) p1[i] = pre[i];
     gload(2);
-    float4 p2[NE];
+    float4 p2[NR];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) { p2[i] = pre[i]; pre[i] = p0[i]; }
+    for (int i = 0; i < NR; ++i) { p2[i] = pre[i]; pre[i] = p0[i]; }
 #pragma unroll
     for (int i = 0; i < NE; ++i) lstore1(0, 0, i);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) pre[i] = p1[i];
+    for (int i = 0; i < NR; ++i) pre[i] = p1[i];
 #pragma unroll
     for (int i = 0; i < NE; ++i) lstore1(1, 1, i);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) pre[i] = p2[i];
+    for (int i = 0; i < NR; ++i) pre[i] = p2[i];
   }
   __syncthreads();
   if (RB_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -212,6 +233,66 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
   RB_STAMP(2);
   if (RB_PRIO) __builtin_amdgcn_s_setprio(RB_PRIO);
 
+  if constexpr (EPI == EPI_UPSAMPLE) {
+    // conv_tile's UPSAMPLE epilogue: virtual row co * u + r of GEMM column q -> y[co][q u + r - up_pad]
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float bb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[r] = a.bias ? a.bias[mt0 * 32 + (r & 3) + 8 * (r >> 2) + rbase] : 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int q = t0 + nb * 32 + col;
+      if (q >= n_len) continue;
+      if ((a.up & 3) == 0 && (a.up_pad & 3) == 0 && (a.y_ld & 3) == 0) {
+        // registers 4g .. 4g+3 of a lane = 4 consecutive phases of ONE output channel = 4 consecutive, 16-byte aligned samples
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int row0 = mt0 * 32 + 8 * g4 + rbase;
+          if (row0 >= a.rows) continue;
+          const int co = row0 / a.up;
+          const int n0 = q * a.up + (row0 - co * a.up) - a.up_pad;
+          float* dst = a.y + (long long)b * a.y_bs + (long long)co * a.y_ld + n0;
+          if (n0 >= 0 && n0 + 3 < Lout) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[nb][4 * g4] + bb[4 * g4], acc[nb][4 * g4 + 1] + bb[4 * g4 + 1],
+                                                          acc[nb][4 * g4 + 2] + bb[4 * g4 + 2], acc[nb][4 * g4 + 3] + bb[4 * g4 + 3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e >= 0 && n0 + e < Lout) dst[e] = acc[nb][4 * g4 + e] + bb[4 * g4 + e];
+          }
+        }
+        continue;
+      }
+      if (a.up == 2) {  // registers (r, r + 1), r even = the two phases of one channel: one (4-byte aligned) 8-byte store per pair
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int row = mt0 * 32 + (r & 3) + 8 * (r >> 2) + rbase;  // even
+          if (row >= a.rows) continue;
+          const int co = row >> 1;
+          const int n0 = q * 2 - a.up_pad;
+          float* dst = a.y + (long long)b * a.y_bs + (long long)co * a.y_ld + n0;
+          const float v0 = acc[nb][r] + bb[r], v1 = acc[nb][r + 1] + bb[r + 1];
+          if (n0 >= 0 && n0 + 1 < Lout && row + 1 < a.rows) {
+            typedef float up_float2 __attribute__((ext_vector_type(2), aligned(4)));
+            *reinterpret_cast<up_float2*>(dst) = up_float2{v0, v1};
+          } else {
+            if (n0 >= 0 && n0 < Lout) dst[0] = v0;
+            if (row + 1 < a.rows && n0 + 1 >= 0 && n0 + 1 < Lout) dst[1] = v1;
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt0 * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row >= a.rows) continue;
+        const int co = row / a.up;
+        const int n = q * a.up + (row - co * a.up) - a.up_pad;
+        if (n < 0 || n >= Lout) continue;
+        a.y[(long long)b * a.y_bs + (long long)co * a.y_ld + n] = acc[nb][r] + bb[r];
+      }
+    }
+  } else {
   // epilogue (conv_tile's LINEAR epilogue without k-groups): y = (acc + bias) [+ res]
   // C/D map of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int col = lane & 31, rbase = 4 * (lane >> 5);
@@ -271,7 +352,23 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
       }
     }
   }
+  }
   RB_STAMP(3);
+}
+
+// one conv per launch on the same tile (the polyphase upsamplers): grid = (time tiles, 128-row tiles, batch rows)
+template <int K, int HALO, int EPI, bool MRF>
+__global__ __launch_bounds__(256, 4) void rb_conv_kernel(const ConvArgs a) {
+  __shared__ float xs[rb_lds_floats<HALO>()];
+  int tile_x, tile_y;
+  int gx = gridDim.x;
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (gridDim.z > 1) {  // ragged batch: this row's own tiles only (conv_mfma.h, row_tiles)
+    gx = row_tiles(conv_n_len<K, EPI>(a, blockIdx.z), 64);
+    if (lin >= gx * (int)gridDim.y) return;
+  }
+  xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
+  rb_tile<K, HALO, EPI, MRF>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // halo of the staged tile per tap count: (K - 1) d for d <= 5, plus the 4-alignment slack of the tile origin

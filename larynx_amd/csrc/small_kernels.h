@@ -10,6 +10,7 @@
 // per-utterance zero padding the un-batched reference has.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "prio.h"
 #include <stdint.h>
 
 namespace mi355tts {
@@ -28,6 +29,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // G1: x[b][c][t] = emb[ids[b][t]][c] * sqrt(H)           (glow_tts/models.py:119-120)
 __global__ void embed_kernel(const long long* ids, int ids_ld, const int* len, const float* emb, int V, int H,
                              float scale, float* x, long long x_bs, int x_ld) {
+  GLOW_PRIO();
   const int b = blockIdx.z;
   const int t = blockIdx.x * 64 + (threadIdx.x & 63);
   const int c0 = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(const float* x, const 
                                                           const int* len, int pre_relu, int post_relu, float eps,
                                                           const float* proj_w = nullptr, const float* proj_b = nullptr,
                                                           float* proj_y = nullptr, long long proj_bs = 0) {
+  GLOW_PRIO();
   __shared__ float red[16][17];
   const int b = blockIdx.y;
   const int tl = threadIdx.x & 15;
@@ -298,11 +301,15 @@ typedef float att_floatx16 __attribute__((ext_vector_type(16)));
 // time is the instruction count of the slowest wave (phase stamps: profiles/NOTES.md).  So: eight waves share
 // every phase, nothing is masked that is never read, addresses advance by one add per load, and every global
 // load whose address is known at entry is issued at entry.  EXACT: dk == 2*NK (no channel clamps at all).
-template <int NK, bool EXACT>  // MFMA k-steps covering the head dimension: 2*NK >= dk
+// PMAXT: the longest sequence this instantiation takes (score rows of PMAXT + 1 floats: 33 KB of LDS at 256, 98 KB at 768 —
+// a loaded CU has the smaller hole far sooner)
+template <int NK, bool EXACT, int PMAXT = ATTM_MAXP>  // MFMA k-steps covering the head dimension: 2*NK >= dk
 __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, long long bs, int ld, const int* len, int H,
                                                              int nheads, int window, const float* ek, const float* ev,
                                                              float* out, long long out_bs, int out_ld) {
-  __shared__ float S[32 * ATTM_PS];
+  GLOW_PRIO();
+  constexpr int PS = PMAXT + 1;  // odd row stride: conflict-free column reads
+  __shared__ float S[32 * PS];
   __shared__ float vs[ATT_MAXDK * 65];  // V chunk [channel][64 keys]; afterwards the k-split partial outputs
   __shared__ float relS[32 * 33];
   __shared__ float evs[ATT_MAXW * ATT_MAXDK];
@@ -383,8 +390,8 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-      float* dst = band ? relS + rbase * 33 + col : S + rbase * ATTM_PS + nb * 32 + col;
-      const int rs = band ? 33 : ATTM_PS;
+      float* dst = band ? relS + rbase * 33 + col : S + rbase * PS + nb * 32 + col;
+      const int rs = band ? 33 : PS;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * rs] = acc[r] * scale;  // keys >= P: never read
     }
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
     const int i = threadIdx.x & 31;
     const int gi = i0 + i;
     const int j = gi + r - window;
-    if (gi < P && j >= 0 && j < P) S[i * ATTM_PS + j] += relS[i * 33 + r];
+    if (gi < P && j >= 0 && j < P) S[i * PS + j] += relS[i * 33 + r];
   }
   __syncthreads();
   ATT_STAMP(5);
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
   // 16 scores stay in registers between the three passes.
   {
     const int sub = lane >> 4, l16 = lane & 15;
-    float* row = S + (wave * 4 + sub) * ATTM_PS;
+    float* row = S + (wave * 4 + sub) * PS;
     if (P <= 256) {
       float e[16];
       float mx = -3.0e38f;
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
     if (unit) {
       const int cl = cb * 32 + col;
       const float* va = vs + min(cl, dk - 1) * 65 + half;
-      const float* pb = S + col * ATTM_PS + j0 + half;
+      const float* pb = S + col * PS + j0 + half;
       const int jn = min(64, jpad - j0);
       for (int jj = 8 * ks; jj < jn; jj += 8 * nks) {  // jn is a multiple of 32
         float a4[4], b4[4];
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
       const int rr = 2 * u + half;
       const int j = gi + rr - window;
       const float a = (rr < nrel && cl < dk) ? evs[rr * ATT_MAXDK + cl] : 0.f;
-      const float p = (rr < nrel && j >= 0 && j < P && gi < P) ? S[col * ATTM_PS + j] : 0.f;
+      const float p = (rr < nrel && j >= 0 && j < P && gi < P) ? S[col * PS + j] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p, acc, 0, 0, 0);
     }
   }
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const float* qkv, l
 // (glow_tts/models.py:323-336).  One workgroup per batch row.
 __global__ void duration_kernel(const float* logw, long long bs, const int* len, float length_scale, int n_sqz,
                                 int* cum, int cum_ld, int* frames, int max_frames_cap) {
+  GLOW_PRIO();
   // one wave per row: lane l owns the contiguous run [l*per, (l+1)*per) of ids, sums its
   // durations, the 64 run totals are scanned with __shfl_up, and the run is walked a second
   // time to write the inclusive cumsum.  Durations are integers (ceil), so the int sum equals
@@ -598,6 +606,7 @@ __global__ void expand_noise_squeeze_kernel(const float* xm, long long xm_bs, in
                                             const int* cum, int cum_ld, const int* frames, const float* noise,
                                             long long noise_bs, int noise_ld, float noise_scale, uint64_t seed,
                                             const unsigned long long* row_seeds, int M, int n_sqz, float* z, long long z_bs, int z_ld) {
+  GLOW_PRIO();
   const int b = blockIdx.z;
   // the noise stream of a row is keyed by the ROW's seed (row_seeds[b], default seed + b) and nothing else: an
   // utterance draws the same field in a batch as in a call of its own with that seed
@@ -686,6 +695,7 @@ __device__ __forceinline__ float mel_transform(float v, const MelTransform& m) {
 __global__ void mel_finalize_kernel(const float* x, long long x_bs, int x_ld, const int* frames, int M, int n_sqz,
                                     float* mel, float* mel_voc, long long mel_bs, int mel_ld, MelTransform mt,
                                     int apply) {
+  GLOW_PRIO();
   const int b = blockIdx.z;
   const int F = frames[b];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -261,11 +261,18 @@ struct hipemuStream { int id; };
 struct hipemuEvent { std::chrono::steady_clock::time_point t; };
 hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemuStream{1}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+  if (least) *least = 0;
+  if (greatest) *greatest = -1;
+  return hipSuccess;
+}
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipemu_check_guards() ? hipErrorUnknown : hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipemu_check_guards() ? hipErrorUnknown : hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // kernels run synchronously at launch
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

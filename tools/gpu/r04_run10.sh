@@ -17,7 +17,7 @@ PY
 }
 for i in 1 2; do
   timeout 300 $B > $O/base_$i.json 2> $O/base_$i.err
-  MI355TTS_M128_MIN_TILES=100 timeout 300 $B > $O/m128s0_$i.json 2> $O/m128s0_$i.err
+  MI355TTS_M128_MIN_TILES=64 timeout 300 $B > $O/m128s0_$i.json 2> $O/m128s0_$i.err
 done
-for c in 12 16; do timeout 300 $B --concurrency $c > $O/conc_$c.json 2> $O/conc_$c.err; done
-show $O/base_1.json $O/m128s0_1.json $O/base_2.json $O/m128s0_2.json $O/conc_12.json $O/conc_16.json
+
+show $O/base_1.json $O/m128s0_1.json $O/base_2.json $O/m128s0_2.json

@@ -128,6 +128,23 @@ __device__ __forceinline__ void run_tile(const ConvGroupArgs& g, int m, int l, f
   else conv_tile<3, CG_CI2, CG_MB, CG_NB, CG_WN, CG_KS, 16, EPI_LINEAR, CG_WM>(g.c[2], tx, ty, 0, xs);
 }
 
+// a launch that does (next to) nothing: what do kernel BOUNDARIES of other streams cost the big launches?
+__global__ void tiny_kernel(float* p, int n) {
+  extern __shared__ float dyn[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = p[i] * 1.0001f + 1.0f;
+  if (n < 0) dyn[threadIdx.x] = p[0];  // (keeps the dynamic LDS allocation alive)
+}
+// a small launch that also WORKS for a few microseconds (a dependent FMA chain per thread), like a GlowTTS conv
+__global__ void small_work_kernel(float* p, int n, int iters) {
+  extern __shared__ float dyn[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = i < n ? p[i] : 0.f;
+  for (int k = 0; k < iters; ++k) v = v * 1.0001f + 0.5f;
+  if (i < n) p[i] = v;
+  if (n < 0) dyn[threadIdx.x] = v;
+}
+
 // dispatch-order variants around the unchanged tile code
 template <bool NEW>
 __global__ __launch_bounds__(NEW ? 256 : NTHREADS, NEW ? RB_LB : CG_LB) void diag_group_kernel(const ConvGroupArgs g, int* ticket) {
@@ -200,6 +217,9 @@ int main(int argc, char** argv) {
       ConvArgs& a = g.c[m];
       a.x = dx; a.x_bs = (long long)C * L; a.x_ld = L; a.in_const = L; a.in_mul = 1;
       a.w = dw[m]; a.bias = db[m]; a.noct = noct[m]; a.Cin = C; a.rows = C; a.dil = CG_DIL; a.pad = CG_DIL * (K - 1) / 2; a.in_slope = 0.1f;
+#ifdef CG_ABLATE  // with -DMI355TTS_ABLATION: conv_tile's ablation bits (1 = no staging after chunk 0, 2 = no A loads, 4 = no barrier)
+      a.ablate = CG_ABLATE;
+#endif
       a.y = dy[s][m]; a.y_bs = (long long)C * L; a.y_ld = L; a.split = 1 << 30; a.alpha = 1.f; a.out_const = L; a.out_mul = 1; a.res = dx;
       g.gx[m] = (L + T_T - 1) / T_T; g.gy[m] = ytiles; g.off[m] = off;
       off += (g.gx[m] * g.gy[m] + 7) & ~7;
@@ -312,6 +332,71 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (N * S);
     printf("%d stream(s): %.1f us per launch (host clock)  %.1f TFLOP/s (%.3f)\n", S, us, flop / us / 1e6, flop / us / 1e6 / 157.3);
+  }
+  // ---- 2b. four streams of the big launch + ONE stream of dependent small launches of a given per-workgroup footprint
+  // (threads, LDS bytes): how long does a small launch take next to the big ones?  (240 workgroups each, like a GlowTTS conv)
+  {
+    ConvGroupArgs g[NSTREAM]; double flop = 0;
+    for (int s = 0; s < NSTREAM; ++s) make(CG_L, s, g[s], flop);
+    hipStream_t es; float* ep;
+    CK(hipStreamCreateWithFlags(&es, hipStreamNonBlocking)); CK(hipMalloc(&ep, 1 << 20)); CK(hipMemset(ep, 0, 1 << 20));
+    const int fp[][2] = {{64, 0}, {256, 16 << 10}, {256, 30 << 10}, {512, 30 << 10}, {256, 60 << 10}, {512, 60 << 10}, {512, 96 << 10}};
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
+    for (auto& f : fp) {
+      CK(hipDeviceSynchronize());
+      const int N = 12, SM = 100;
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int s = 0; s < NSTREAM; ++s) for (int i = 0; i < 3; ++i) launch(g[s], st[s], s);  // the load is up before the small stream starts
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < N; ++i)
+        for (int s = 0; s < NSTREAM; ++s) launch(g[s], st[s], s);
+      CK(hipEventRecord(e0, es));
+      for (int k = 0; k < SM; ++k) hipLaunchKernelGGL(tiny_kernel, dim3(240), dim3(f[0]), f[1], es, ep, 240 * f[0]);
+      CK(hipEventRecord(e1, es));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      for (int s = 0; s < NSTREAM; ++s) CK(hipStreamSynchronize(st[s]));
+      const double us_big = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (N * NSTREAM);
+      printf("small launches of 240 x (%d threads, %d KB LDS) next to 4 big streams: %.1f us per small launch; big launches %.1f us each\n", f[0], f[1] >> 10,
+             1e3 * ms / SM, us_big);
+    }
+  }
+  // ---- 2c. four big streams + K streams of dependent small WORKING launches (240 x 512 threads, 30 KB LDS, ~5 us alone):
+  // does the aggregate rate of small launches grow with K, or is it capped?
+  {
+    ConvGroupArgs g[NSTREAM]; double flop = 0;
+    for (int s = 0; s < NSTREAM; ++s) make(CG_L, s, g[s], flop);
+    const int KMAX = 8;
+    hipStream_t es[KMAX]; float* ep[KMAX];
+    for (int k = 0; k < KMAX; ++k) { CK(hipStreamCreateWithFlags(&es[k], hipStreamNonBlocking)); CK(hipMalloc(&ep[k], 1 << 20)); CK(hipMemset(ep[k], 0, 1 << 20)); }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(small_work_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
+    {  // alone
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, es[0]));
+      for (int k = 0; k < 200; ++k) hipLaunchKernelGGL(small_work_kernel, dim3(240), dim3(512), 30 << 10, es[0], ep[0], 240 * 512, 600);
+      CK(hipEventRecord(e1, es[0])); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("small working launch alone: %.1f us each\n", 1e3 * ms / 200);
+    }
+    for (int K : {1, 2, 4, 8}) {
+      CK(hipDeviceSynchronize());
+      const int N = 10, SM = 60;
+      for (int s = 0; s < NSTREAM; ++s) for (int i = 0; i < 3; ++i) launch(g[s], st[s], s);
+      hipEvent_t e0[KMAX], e1[KMAX];
+      for (int k = 0; k < K; ++k) { CK(hipEventCreate(&e0[k])); CK(hipEventCreate(&e1[k])); }
+      for (int i = 0; i < N; ++i)
+        for (int s = 0; s < NSTREAM; ++s) launch(g[s], st[s], s);
+      for (int k = 0; k < K; ++k) CK(hipEventRecord(e0[k], es[k]));
+      for (int j = 0; j < SM; ++j)
+        for (int k = 0; k < K; ++k) hipLaunchKernelGGL(small_work_kernel, dim3(240), dim3(512), 30 << 10, es[k], ep[k], 240 * 512, 600);
+      for (int k = 0; k < K; ++k) CK(hipEventRecord(e1[k], es[k]));
+      double tot = 0;
+      for (int k = 0; k < K; ++k) { CK(hipEventSynchronize(e1[k])); float ms; CK(hipEventElapsedTime(&ms, e0[k], e1[k])); tot += ms; }
+      CK(hipDeviceSynchronize());
+      printf("%d chain(s) of small working launches next to 4 big streams: %.1f us per launch per chain -> aggregate %.0f launches/ms\n", K, 1e3 * tot / K / SM,
+             K * SM / (tot / K));
+    }
   }
   // ---- 3. timeline of one launch in steady state (the 3rd of 4 back-to-back launches)
   {
