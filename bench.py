@@ -336,6 +336,10 @@ def main():
                     help="how many times the K-step region is timed (each bracketed by barrier + synchronize); the line "
                          "reports the median.  0 = as many as fit ~2 s, at least 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the 10 x K-step regions reported as `steady_state`")
+    ap.add_argument("--voc-only-sleep-ms", type=float, default=0.0,
+                    help="probe: in the vocoder-only region every call first sleeps this long on the host (stands in for the latency "
+                         "of an acoustic pass that uses no GPU at all)")
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-half-mode", action="store_true", help="skip the secondary bf16x3 (`half` switch) leg")
     ap.add_argument("--config3-utterances", type=int, default=256)
@@ -577,6 +581,35 @@ def main():
         eng.set_option("glow_coalesce", 0)
         run_steps(0, max(W, conc))
     t_dn = timed(lambda: run_steps(W, n_utts, denoiser=0.005), max(3, repeats // 3)) if dn_ok else [float("nan")]
+    # ---- steady state: the SAME calls in regions ten times as long.  A K-step region starts on an idle GPU (every caller begins
+    # with its acoustic pass: ~2 ms before the first vocoder launch) and drains at its end (the last calls run with fewer and
+    # fewer others to fill their launches' tails); at K = 20 that is ~4 % of a 74 ms region.  Reported next to the headline,
+    # which keeps the K-step definition.
+    t_steady, K_steady = None, 0
+    if conc > 1 and not args.tiny and not args.no_steady_state:
+        K_steady = 10 * K
+
+        def run_long():
+            if pool is None:
+                return sum(step(W + (j % K)) for j in range(K_steady))
+            import itertools
+            import queue
+
+            q = queue.SimpleQueue()
+            for j in range(K_steady):
+                q.put(W + (j % K))
+
+            def work(slot):
+                while True:
+                    try:
+                        i = q.get_nowait()
+                    except queue.Empty:
+                        return
+                    step(i, slot)
+
+            list(pool.map(work, range(conc)))
+
+        t_steady = timed(run_long, 3)
     # host CPU seconds (all threads of this process) over one more pass of the headline region: what a rank costs the host
     # per utterance — the one term of the 1 -> 8 GPU curve that the ranks share (8 ranks x `conc` threads on one host)
     barrier()
@@ -587,12 +620,14 @@ def main():
     # what GlowTTS costs UNDER LOAD: the same K steps with the acoustic model taken out — every call is the vocoder alone on
     # the device-resident mel GlowTTS produced for that utterance (same in-flight count, same buffers); the difference to the
     # headline region is GlowTTS's price per utterance when its launches compete with other calls' vocoder launches
-    t_voc = None
+    t_voc = t_voc_steady = None
     if B == 1 and not args.tiny:
         mels = {i: eng.glow_infer_raw(g, ids_dev[i].data_ptr(), lens, args.ids, 0.667, args.length_scale, seed=1234 + i, audio_settings=s,
                                       flags=ffi.IN_DEVICE) for i in range(W, n_utts)}
         if mels:
             def voc_step(i, slot):
+                if args.voc_only_sleep_ms > 0:
+                    time.sleep(args.voc_only_sleep_ms * 1e-3)
                 eng.hifigan_infer_raw(v, mels[i], wav_f32[slot].data_ptr(), wav_i16[slot].data_ptr(), max_samples, flags=ffi.OUT_DEVICE)
 
             def run_voc():
@@ -618,6 +653,25 @@ def main():
 
             run_voc()
             t_voc = timed(run_voc, max(3, repeats // 3))
+            if t_steady:  # the vocoder-only region at the steady-state length too
+                def run_voc_long():
+                    import queue
+
+                    q = queue.SimpleQueue()
+                    for j in range(K_steady):
+                        q.put(W + (j % K))
+
+                    def work(slot):
+                        while True:
+                            try:
+                                i = q.get_nowait()
+                            except queue.Empty:
+                                return
+                            voc_step(i, slot)
+
+                    list(pool.map(work, range(conc)))
+
+                t_voc_steady = timed(run_voc_long, 3)
             for m_ in mels.values():
                 m_.free()
 
@@ -647,7 +701,8 @@ def main():
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
                           half[0] if half else 0.0, half[1] if half else 0.0, med(t_flight_nc), med(t_voc) if t_voc else 0.0,
-                          host_cpu_s, host_wall_s], dtype=torch.float64, device=red_dev)
+                          host_cpu_s, host_wall_s, med(t_steady) if t_steady else 0.0, med(t_voc_steady) if t_voc_steady else 0.0],
+                         dtype=torch.float64, device=red_dev)
     per_rank = [[float(stats[0]), float(stats[1])]]  # this rank's (in-flight, single-stream) seconds per K-step region
     if use_dist:
         gathered = [None] * world
@@ -662,7 +717,7 @@ def main():
     else:
         total_frames = float(frames)
     (dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single, dt_flight_nc, dt_voc,
-     host_cpu_max, host_wall_max) = (float(x) for x in stats)
+     host_cpu_max, host_wall_max, dt_steady, dt_voc_steady) = (float(x) for x in stats)
 
     # ---- BASELINE config 3: 256 utterances, LPT-sharded over the ranks, ordered gather (strong scaling)
     c3 = None
@@ -852,6 +907,16 @@ def main():
             # process — the Python callers, ctypes, the HIP runtime's launch path (~170 launches per utterance)
             "host_cpu_ms_per_utterance": 1e3 * host_cpu_max / (K * B),
             "host_cpu_cores_busy_per_rank": host_cpu_max / host_wall_max if host_wall_max > 0 else None,
+            "steady_state": None if dt_steady <= 0 else {
+                "what": f"the same calls, the same {conc} in flight, in timed regions of {K_steady} steps instead of {K} (3 repeats, median; same "
+                        "bracketing).  NOT the headline: `value` keeps the K-step region, which starts on an idle GPU (every caller begins "
+                        "with its acoustic pass) and drains at its end — about 4 % of a 74 ms region at K = 20",
+                "steps": K_steady,
+                "utterances_per_sec": world * K_steady * B / dt_steady,
+                "ms_per_step": 1e3 * dt_steady / K_steady,
+                "vocoder_only_utterances_per_sec": None if dt_voc_steady <= 0 else world * K_steady * B / dt_voc_steady,
+                "glow_under_load_ms": None if dt_voc_steady <= 0 else 1e3 * (dt_steady - dt_voc_steady) / K_steady,
+            },
             "glow_under_load_ms": None if dt_voc <= 0 else 1e3 * (dt_flight - dt_voc) / K,
             "vocoder_only_under_load": None if dt_voc <= 0 else {
                 "what": "the headline region with GlowTTS taken out: the same K utterances, the same calls in flight, each call the vocoder "

@@ -385,4 +385,53 @@ PY
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed"
 }
 
+ab_voc_only_sleep() {
+# the vocoder-only region of bench.py with a HOST sleep in front of every call (an acoustic pass that takes its under-load
+# latency but no GPU): how much of glow_under_load_ms is latency (callers not feeding the GPU), how much is GPU work?
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab10; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode"
+for c in 8 16; do for ms in 0 4 8 12; do timeout 300 $B --concurrency $c --voc-only-sleep-ms $ms > $O/c${c}_s$ms.json 2> $O/c${c}_s$ms.err; done; done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab10/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1][:-5], "full call %.1f /s" % j["value"], "vocoder-only region (with the sleep) %.1f /s" % j["vocoder_only_under_load"]["utterances_per_sec"])
+PY
+}
+
+ab_steps() {
+# value against the number of steps K of a timed region (each region starts on an idle GPU and drains at its end)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab11; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode"
+for k in 20 50 100 200 400; do timeout 600 $B --steps $k > $O/k$k.json 2> $O/k$k.err; done
+timeout 600 $B --steps 200 --concurrency 12 > $O/k200_c12.json 2> $O/k200_c12.err
+timeout 600 $B --steps 200 --concurrency 16 > $O/k200_c16.json 2> $O/k200_c16.err
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab11/*.json"), key=lambda x: (len(x), x)):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); gc = j.get("glow_coalescing") or {}
+    print(f.split("/")[-1][:-5], "value %.1f /s" % j["value"], "ms_per_step %.3f" % j["ms_per_step"], "vocoder-only %.1f /s" % j["vocoder_only_under_load"]["utterances_per_sec"], "glow_under_load %.3f" % j["glow_under_load_ms"],
+          "latency %.3f" % j["latency_ms_single_stream"], "repeats %d" % j["timing"]["repeats"], "coalesced %.1f (%.1f rows)" % (gc.get("utterances_per_sec", 0), gc.get("rows_per_pass", 0)))
+PY
+}
+
+ab_stage0_m128_steady() {
+# the 128-row continuous-stream tile for the 256-channel stage too (MI355TTS_M128_MIN_TILES=64), read in the steady-state leg
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab12; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode"
+for i in 1 2; do
+  timeout 600 $B > $O/base_$i.json 2> $O/base_$i.err
+  MI355TTS_M128_MIN_TILES=64 timeout 600 $B > $O/m128_$i.json 2> $O/m128_$i.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab12/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "steady %.1f" % j["steady_state"]["utterances_per_sec"], "vocoder-only %.1f" % j["vocoder_only_under_load"]["utterances_per_sec"], "latency %.3f" % j["latency_ms_single_stream"], "frac %.4f" % j["roofline"]["frac"])
+PY
+}
+
 "$@"

@@ -63,6 +63,32 @@ def two_call(n_threads):
           f"(p90 {1e3 * np.percentile(tg, 90):.2f}), vocoder phase {1e3 * np.median(tv):.2f} ms (p90 {1e3 * np.percentile(tv, 90):.2f})")
 
 
+def sleep_then_vocoder(n_threads, sleep_ms):
+    """The acoustic pass replaced by a HOST sleep of its under-load duration: is it the GPU work of GlowTTS that costs the
+    vocoder calls, or only that a caller does not feed the GPU while its pass crawls?"""
+    mels = [eng.glow_infer(g, ids[i % 16], 0.667, 0.65, seed=i, audio_settings=s) for i in range(n_threads)]
+    bar = threading.Barrier(n_threads + 1)
+
+    def worker(i):
+        for k in range(ncall + 3):
+            if k == 3:
+                bar.wait()
+            time.sleep(sleep_ms * 1e-3)
+            eng.hifigan_infer(v, mels[i], want_float=False, want_int16=True)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for m in mels:
+        m.free()
+    print(f"{n_threads} threads, host sleep {sleep_ms} ms then vocoder per call: {n_threads * ncall / dt:.1f} utterances/s")
+
+
 def staged(n_voc, n_glow, depth=16):
     total = n_voc * ncall
     q = queue.Queue(maxsize=depth)
@@ -115,10 +141,12 @@ def staged(n_voc, n_glow, depth=16):
           f"vocoder call {1e3 * np.median(tv):.2f} ms")
 
 
+eng.reserve(34, g, v, max_batch=1, max_ids=120, max_frames=1024)
 for r in range(2):
     two_call(nthr)
+    two_call(16)
+    for n, ms in ((8, 0.0), (8, 4.0), (8, 8.0), (8, 12.0), (12, 8.0), (16, 8.0), (16, 12.0), (24, 12.0)):
+        sleep_then_vocoder(n, ms)
     staged(nthr, 1)
     staged(nthr, 2)
-    staged(nthr - 1, 1)
-    staged(6, 2)
 eng.close()
