@@ -39,6 +39,17 @@ def check_synthesize_equals_two_calls(eng, g, v, num_symbols, hop, lens=(13, 7, 
         for b in range(len(frames)):
             n = int(frames[b]) * hop
             assert np.array_equal(i1[b, 5 : 5 + n], i0[b, :n])
+    # option "glow_priority": the acoustic pass on a priority stream of the call's worker, the vocoder behind an event — same bits
+    eng.set_option("glow_priority", 1)
+    try:
+        for ids in (rows[0], rows):
+            ref = eng.synthesize(g, v, ids, 0.667, 1.0, seed=99, audio_settings=s, want_float=True)
+            eng.set_option("glow_priority", 0)
+            off = eng.synthesize(g, v, ids, 0.667, 1.0, seed=99, audio_settings=s, want_float=True)
+            eng.set_option("glow_priority", 1)
+            assert all(np.array_equal(a, b) for a, b in zip(ref, off))
+    finally:
+        eng.set_option("glow_priority", 0)
     # a guess that is too small is retried with a bigger buffer
     frames, _, i3 = eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9, frames_per_id_guess=0.2)
     assert np.array_equal(i3, eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9)[2])
