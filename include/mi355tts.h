@@ -240,7 +240,10 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * (and, with "mrf_group" = 0, do not fork the chains onto side streams); "gate16", "glow_fuse", "mrf_small" (0/1, default 1)
  * — the small-launch kernels of gate16.h / coltile.h / mrf_small.h (0 = the generic tiles; same results up to summation
  * order); "rb_conv" (0/1, default 1) — the grouped 128-row ResBlock launches on the continuous-stream tile of rb_conv.h
- * (0 = the chunked tile of conv_mfma.h; same bits); "glow_coalesce" (below).  The schedule options give the same bits under
+ * (0 = the chunked tile of conv_mfma.h; same bits); "rb_pair" (0/1, default 1) — the fused ResBlock steps of the 64- / 32-channel
+ * stages on the 4-wave tile without a k-split (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h: same results up to
+ * summation order); "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
+ * the call's worker; "glow_coalesce" (below).  The schedule options give the same bits under
  * every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 /* Option "glow_coalesce" (0/1, default 0): concurrent batch-1 mi355tts_synthesize calls (the reference's per-sentence

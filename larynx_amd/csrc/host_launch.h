@@ -555,6 +555,16 @@ static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t
 #undef PAIR16_LAUNCH
     return 0;
   }
+  if (w->o_rb_pair) {  // the 4-wave tile without a k-split (rb_pair.h): same tiles and arguments
+#define RBP_LAUNCH(KK)                                                                                               \
+  if (p.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_kernel<KK, 1>), grid, dim3(256), 0, s, a);               \
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_kernel<KK, 2>), grid, dim3(256), 0, s, a)
+    if (p.K == 3) { RBP_LAUNCH(3); }
+    else if (p.K == 7) { RBP_LAUNCH(7); }
+    else { RBP_LAUNCH(11); }
+#undef RBP_LAUNCH
+    return 0;
+  }
 #define PAIR_LAUNCH(KK, CB, NBB) hipLaunchKernelGGL(HIP_KERNEL_NAME(resblock_pair_kernel<KK, CB, NBB>), grid, dim3(512), 0, s, a)
 #define PAIR_K(KK)                                  \
   if (p.C == 32) PAIR_LAUNCH(KK, 1, 2);             \
@@ -603,6 +613,11 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   if (p0.bf16 == 1) {
     if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 1, P16_WN32, P16_NB32, 1>), grid, dim3(64 * P16_WN32), 0, s, g);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 2, P16_WN64, P16_NB64, 1>), grid, dim3(128 * P16_WN64), 0, s, g);
+    return 0;
+  }
+  if (w->o_rb_pair) {
+    if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_group_kernel<11, 7, 3, 1>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_group_kernel<11, 7, 3, 2>), grid, dim3(256), 0, s, g);
     return 0;
   }
   if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_group_kernel<11, 7, 3, 1, 2>), grid, dim3(512), 0, s, g);

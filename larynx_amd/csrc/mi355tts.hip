@@ -29,6 +29,7 @@
 #include "conv_mfma.h"
 #include "rb_conv.h"
 #include "resblock_pair.h"
+#include "rb_pair.h"
 #include "conv_bf16.h"
 #include "resblock_pair_bf16.h"
 #include "mrf_small.h"
@@ -1174,6 +1175,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "rb_conv") == 0) {
     ctx->rb_conv = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "rb_pair") == 0) {
+    ctx->rb_pair = value != 0;
     return 0;
   }
   if (std::strcmp(name, "glow_priority") == 0) {

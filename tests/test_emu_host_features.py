@@ -389,3 +389,38 @@ def test_continuous_stream_tile_equals_the_chunked_tile(emu_engine, monkeypatch)
             assert np.isfinite(new).all() and np.abs(new).max() > 1e-3
     finally:
         emu_engine.unload(v)
+
+
+def test_four_wave_pair_kernel_against_the_k_split_one(emu_engine):
+    """`rb_pair_kernel` / `rb_pair_group_kernel` (rb_pair.h: 4 waves, no k-split, the parked conv1 tile over the x tile) run the
+    fused ResBlock steps of the 64- / 32-channel stages by default; option "rb_pair" = 0 sends them to the 8-wave k-split
+    kernel of resblock_pair.h.  Same tiles and arithmetic up to the summation order: the waveforms agree to f32 round-off, in
+    the grouped and in the one-launch-per-step schedule, rows of different lengths and tile-edge lengths included."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)), num_mels=16)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=94)
+    v = emu_engine.load_hifigan(hp, sd)
+    rng = np.random.default_rng(13)
+    try:
+        for frames in ([61], [70, 33], [30]):
+            F = max(frames)
+            mel = (0.5 + 0.1 * rng.standard_normal((len(frames), hp.num_mels, F))).astype(np.float32)
+            mb = emu_engine.mel_from_numpy(mel, np.array(frames, np.int32))
+            new, _ = emu_engine.hifigan_infer(v, mb)
+            emu_engine.set_option("serial_branches", 1)
+            try:
+                new_serial, _ = emu_engine.hifigan_infer(v, mb)
+            finally:
+                emu_engine.set_option("serial_branches", 0)
+            emu_engine.set_option("rb_pair", 0)
+            try:
+                old, _ = emu_engine.hifigan_infer(v, mb)
+            finally:
+                emu_engine.set_option("rb_pair", 1)
+            assert np.isfinite(new).all() and np.abs(new).max() > 1e-3
+            assert np.sqrt(np.mean((new - old) ** 2)) <= 2e-6 and np.abs(new - old).max() <= 2e-5
+            assert np.sqrt(np.mean((new - new_serial) ** 2)) <= 2e-6  # (the serial form folds the MRF average elsewhere)
+            for b, f in enumerate(frames):
+                assert np.all(new[b, f * hp.hop:] == 0)
+    finally:
+        emu_engine.unload(v)

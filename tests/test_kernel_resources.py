@@ -132,6 +132,15 @@ def test_continuous_stream_tile_resources(resources):
         assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["lds"] == 32 * 1024 and r["occupancy"] >= 4, (n, r)
 
 
+def test_four_wave_pair_kernel_resources(resources):
+    """rb_pair_kernel / rb_pair_group_kernel (rb_pair.h): no scratch; C = 64 at <= 168 VGPRs and 47 KB (three workgroups per
+    CU), C = 32 at <= 168 VGPRs and 40 KB."""
+    rbp = {n: r for n, r in resources.items() if "rb_pair_group_kernel" in n or "rb_pair_kernel" in n}
+    assert len(rbp) == 8, sorted(rbp)  # 3 tap counts x 2 channel counts + 2 grouped
+    for n, r in rbp.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 168 and r["lds"] <= 48 * 1024 and r["occupancy"] >= 3, (n, r)
+
+
 def test_two_workgroups_per_cu_where_the_schedule_counts_on_it(resources):
     conv = conv_variants(resources)
     assert conv

@@ -434,4 +434,53 @@ for f in sorted(glob.glob("gpurun_out/r04_ab12/*.json")):
 PY
 }
 
+ab_rb_pair() {
+# the 4-wave fused pair kernel without a k-split (rb_pair.h, option rb_pair) vs the 8-wave one: kernel stats, bench, parity
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab13; mkdir -p $O
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in old new; do
+  opt=""; [ $v = old ] && opt="--set-option rb_pair=0"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/t_$v -o t --output-format csv -- $B $opt > $O/t_$v.log 2>&1
+  f=$(find $O/t_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; grep -E "pair" $f | cut -c1-150
+  rm -rf $O/t_$v
+done
+B2="python bench.py --no-cpu-baseline --no-config3 --no-config5 --no-half-mode"
+for i in 1 2; do
+  timeout 300 $B2 --set-option rb_pair=0 > $O/old_$i.json 2> $O/old_$i.err
+  timeout 300 $B2 > $O/new_$i.json 2> $O/new_$i.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab13/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); p = j["profile_ms_per_step"]
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "steady %.1f" % j["steady_state"]["utterances_per_sec"], "lat %.3f" % j["latency_ms_single_stream"], "frac %.4f" % j["roofline"]["frac"],
+          "resblock %.3f" % p["conv_mfma.hifigan_resblock"], "config4 %.0f (%.3f ms single)" % (j["config4"]["utterances_per_sec"], j["config4"]["latency_ms_single_stream"]))
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
+}
+
+ab_rb_pair_variants() {
+# rb_pair.h variants: conv2's bias / residual requested before its MFMA phase (-DRBP_PREFETCH64 / 32), the C = 32 kernel at
+# three waves per SIMD (-DRBP_LB32=3); libraries built with those switches next to the default one
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab14; mkdir -p $O
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in "" _p64 _lb3 _p64_p32lb3; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/t$v -o t --output-format csv -- $B --library larynx_amd/libmi355tts$v.so > $O/t$v.log 2>&1
+  f=$(find $O/t$v -name "*kernel_stats.csv" | head -1)
+  echo "== lib$v"; grep -E "pair" $f | cut -c1-140
+  rm -rf $O/t$v
+done
+B2="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode"
+for i in 1 2; do for v in "" _p64 _lb3 _p64_p32lb3; do timeout 300 $B2 --library larynx_amd/libmi355tts$v.so > $O/lib${v}_$i.json 2> $O/lib${v}_$i.err; done; done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab14/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); p = j["profile_ms_per_step"]
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "steady %.1f" % j["steady_state"]["utterances_per_sec"], "lat %.3f" % j["latency_ms_single_stream"], "frac %.4f" % j["roofline"]["frac"], "resblock %.3f" % p["conv_mfma.hifigan_resblock"])
+PY
+}
+
 "$@"
