@@ -489,6 +489,7 @@ struct PairPlan {
   double flop = 0;
   bool ok = false;  // geometry covered by the fused kernel
   int bf16 = 0;     // 0 = f32 kernel (resblock_pair.h); 3 / 1 = split / plain bf16 kernel (resblock_pair_bf16.h)
+  bool rb = false;  // f32: the 4-wave tile without a k-split (rb_pair.h) — launches with enough tiles (see plan_pair)
 };
 static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, float* y, long long bs, int ld, const int* len,
                       int len_mul, int dil, float alpha, int accum, int B, int Lmax, int host_len, PairPlan* out, int precision = 0) {
@@ -531,6 +532,16 @@ static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, floa
   a.nslab = c1.nslab16;
   const int T2 = 128 * out->NB - (K - 1);
   out->grid = dim3((Lmax + T2 - 1) / T2, 1, B);
+  {
+    // The 4-wave tile (three workgroups of 4 waves per CU) wins where a launch has many tiles ('high' at batch 1: 1300 per
+    // member: -5 ... -9 % per launch); with a few dozen tiles per member (the 64-channel stage of 'medium': 42 at batch 1,
+    // ~150 over config 4's ragged batch) the 8-wave k-split tile finishes a tile twice as fast and wins (97 vs 132 us).  The
+    // count is the k = 11 member's, so the three members of a grouped launch always agree.
+    const char* e = std::getenv("MI355TTS_RB_PAIR_MIN_TILES");  // (read per plan, like MI355TTS_M128_MIN_TILES: tests lower it)
+    const long long min_tiles = e ? std::atoll(e) : 512LL;
+    const int t2_ref = 128 * out->NB - 10;
+    out->rb = !half && (long long)((Lmax + t2_ref - 1) / t2_ref) * B >= min_tiles;
+  }
   out->flop = 2.0 * 2.0 * (double)C * C * K * (double)Lmax * B;
   out->ok = true;
 }
@@ -555,7 +566,7 @@ static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t
 #undef PAIR16_LAUNCH
     return 0;
   }
-  if (w->o_rb_pair) {  // the 4-wave tile without a k-split (rb_pair.h): same tiles and arguments
+  if (w->o_rb_pair && p.rb) {  // the 4-wave tile without a k-split (rb_pair.h): same tiles and arguments
 #define RBP_LAUNCH(KK)                                                                                               \
   if (p.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_kernel<KK, 1>), grid, dim3(256), 0, s, a);               \
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_kernel<KK, 2>), grid, dim3(256), 0, s, a)
@@ -587,7 +598,7 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   const PairPlan& p0 = plans[ord[0]];
   for (int i = 0; i < 3; ++i) {
     const PairPlan& p = plans[ord[i]];
-    if (!p.ok || p.C != p0.C || p.NB != p0.NB || p.grid.z != p0.grid.z || p.bf16 != p0.bf16) return 1;
+    if (!p.ok || p.C != p0.C || p.NB != p0.NB || p.grid.z != p0.grid.z || p.bf16 != p0.bf16 || p.rb != p0.rb) return 1;
   }
   if (!(plans[ord[0]].K == 11 && plans[ord[1]].K == 7 && plans[ord[2]].K == 3)) return 1;
   if (!p0.bf16 && !((p0.C == 32 && p0.NB == 2) || (p0.C == 64 && p0.NB == 1))) return 1;
@@ -615,7 +626,7 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 2, P16_WN64, P16_NB64, 1>), grid, dim3(128 * P16_WN64), 0, s, g);
     return 0;
   }
-  if (w->o_rb_pair) {
+  if (w->o_rb_pair && p0.rb) {
     if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_group_kernel<11, 7, 3, 1>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_pair_group_kernel<11, 7, 3, 2>), grid, dim3(256), 0, s, g);
     return 0;

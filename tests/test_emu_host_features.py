@@ -391,11 +391,13 @@ def test_continuous_stream_tile_equals_the_chunked_tile(emu_engine, monkeypatch)
         emu_engine.unload(v)
 
 
-def test_four_wave_pair_kernel_against_the_k_split_one(emu_engine):
+def test_four_wave_pair_kernel_against_the_k_split_one(emu_engine, monkeypatch):
     """`rb_pair_kernel` / `rb_pair_group_kernel` (rb_pair.h: 4 waves, no k-split, the parked conv1 tile over the x tile) run the
     fused ResBlock steps of the 64- / 32-channel stages by default; option "rb_pair" = 0 sends them to the 8-wave k-split
     kernel of resblock_pair.h.  Same tiles and arithmetic up to the summation order: the waveforms agree to f32 round-off, in
-    the grouped and in the one-launch-per-step schedule, rows of different lengths and tile-edge lengths included."""
+    the grouped and in the one-launch-per-step schedule, rows of different lengths and tile-edge lengths included.  (Launches
+    with fewer than 512 tiles per member keep the k-split kernel: `MI355TTS_RB_PAIR_MIN_TILES` lowers that for emulator sizes.)"""
+    monkeypatch.setenv("MI355TTS_RB_PAIR_MIN_TILES", "1")
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)), num_mels=16)
     sd = synthetic.make_hifigan_state_dict(hp, seed=94)
