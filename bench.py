@@ -303,7 +303,7 @@ def config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_
                 "algorithmic_gbytes_per_s": narrow_bytes * K / (narrow["ms"] * 1e-3) / 1e9 if narrow["ms"] > 0 else None,
             },
             "wide_stages": {
-                "kernel": "pair_group_kernel (fused conv pairs, 64- and 32-channel stages)",
+                "kernel": "pair_group_kernel / rb_pair_group_kernel (fused conv pairs, 64- and 32-channel stages: the 8-wave k-split tile below 512 tiles per member, the four-wave tile above)",
                 "bound": "mfma", "achieved": tf(wide), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (tf(wide) or 0.0) / FP32_PEAK_TFLOPS,
                 "launches": wide["launches"], "avg_launch_us": 1e3 * wide["ms"] / max(1, wide["launches"]),
@@ -981,7 +981,7 @@ def main():
             "host_affinity_rank0": affinity,
             "process_group": (("nccl (RCCL)" if rccl else ("gloo" if not on_gpu else f"gloo (RCCL init failed: {pg_note}); every rank folded its own seeded weights")) if use_dist else None),
             "roofline": {
-                "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256/128-channel stages) + pair_group_kernel (fused conv pairs, 64/32-channel stages)",
+                "kernel": "HiFi-GAN ResBlock launches: conv_group_kernel (256-channel stage), rb_group_kernel (128-channel stage, the continuous-stream tile of rb_conv.h), rb_pair_group_kernel (fused conv pairs of the 64/32-channel stages on four waves, rb_pair.h)",
                 "bound": "mfma",
                 "achieved": dom_tf,
                 "peak": FP32_PEAK_TFLOPS,
@@ -1000,7 +1000,7 @@ def main():
                 "schedule": ("serial_branches=1: one conv (or fused conv pair) per launch, the three MRF chains one after another "
                              "on one stream" if args.serial_branches else
                              "product schedule: one stream per call; the same-geometry convs (or fused conv pairs) of the three MRF "
-                             "chains of a step are ONE grouped launch (conv_group_kernel / pair_group_kernel), each launch timed alone"),
+                             "chains of a step are ONE grouped launch (conv_group_kernel / rb_group_kernel / rb_pair_group_kernel), each launch timed alone"),
                 "timing": "HIP events on the launch stream around every launch, profiled pass of the same K steps",
             },
             "profile_ms_per_step": {k_: v_["ms"] / K for k_, v_ in prof.items()},

@@ -31,23 +31,24 @@ namespace mi355tts {
 #endif
 
 // ring buffer stride: whole sweeps of the 256 threads (a thread past the tile's last float4 stores into padding)
-template <int HALO>
-constexpr int rb_buf_floats() { return ((16 * (64 + HALO) / 4 + 255) / 256) * 256 * 4; }
-template <int HALO>
-constexpr int rb_lds_floats() { return 4 * rb_buf_floats<HALO>(); }
+template <int HALO, int NB = 2>
+constexpr int rb_buf_floats() { return ((16 * (32 * NB + HALO) / 4 + 255) / 256) * 256 * 4; }
+template <int HALO, int NB = 2>
+constexpr int rb_lds_floats() { return 4 * rb_buf_floats<HALO, NB>(); }
 
 // One workgroup (4 waves = 4 row groups of 32 rows) = rows [128 tile_y, +128) x columns [64 tile_x, +64) of batch row b.
 // EPI_LINEAR: ConvArgs x (no x2 / x3), bias, res, y; alpha = 1, no accumulate / activation / row split (the host checks).
 // EPI_UPSAMPLE: the polyphase ConvTranspose1d of conv_tile (K = 2 taps, rows = C_out * u virtual rows scattered to
 // q u + r - pad), optionally with MRF = the consumer-side MRF average: input = ((x + x2) + x3) / in_div, summed when the
 // tile is written to LDS — the three planes' loads go out together a chunk earlier, nothing waits for them.
-template <int K, int HALO, int EPI = EPI_LINEAR, bool MRF = false>
+template <int K, int HALO, int EPI = EPI_LINEAR, bool MRF = false, int NB = 2>
 __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
   static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "rb_tile: linear and upsample epilogues");
-  constexpr int CI_C = 16, NB = 2, NT = 256, T_T = 64;
+  constexpr int CI_C = 16, NT = 256, T_T = 32 * NB;  // NB column blocks of 32 per wave: 64-column tiles, or 32 (NB = 1) where a
+  // launch would otherwise have too few workgroups (the 256-channel stage at batch 1)
   constexpr int XW = T_T + HALO, XW4 = XW / 4, OCTS = CI_C / 8, S = OCTS * K;
   constexpr int NF4 = CI_C * XW4, NE = (NF4 + NT - 1) / NT;
-  constexpr int BUF = rb_buf_floats<HALO>();  // floats per ring buffer (>= CI_C * XW)
+  constexpr int BUF = rb_buf_floats<HALO, NB>();  // floats per ring buffer (>= CI_C * XW)
   static_assert(BUF == NE * NT * 4, "ring stride = whole thread sweeps");
   static_assert(XW % 4 == 0 && S >= NE + 2, "bad tile parameters");
 
@@ -200,6 +201,9 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) bnxt[j][nb] = bp[(2 * j) * XW + nb * 32];
       }
+      // one accumulator (NB = 1): every MFMA depends on the previous one and a filler between two dependent MFMAs costs
+      // ~40 cycles (MI355X_MICROARCH.md) — the fillers go first, the MFMAs stay back to back
+      if constexpr (NB == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 af = ar[s % RD];
@@ -207,12 +211,14 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[j][nb], acc[nb], 0, 0, 0);
       }
-      // every filler (the fragment load, the LDS reads of the next step) in the shadow of an MFMA
+      // two accumulators: every filler (the fragment load, the LDS reads of the next step) in the shadow of an MFMA
+      if constexpr (NB >= 2) {
 #pragma unroll
-      for (int i = 0; i < 4 * NB; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        else if (i < 1 + 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < 4 * NB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          else if (i < 1 + 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(RB_ABL & 8)) {
@@ -378,10 +384,10 @@ template <> struct RbCfg<7> { static constexpr int HALO = 36; };
 template <> struct RbCfg<3> { static constexpr int HALO = 16; };
 
 // the three MRF chains' same-geometry convs in one launch, longest first (cf. conv_group_kernel)
-template <int K0, int K1, int K2>
+template <int K0, int K1, int K2, int NB = 2>
 __global__ __launch_bounds__(256, 4) void rb_group_kernel(const ConvGroupArgs g) {
   constexpr int H0 = RbCfg<K0>::HALO, H1 = RbCfg<K1>::HALO, H2 = RbCfg<K2>::HALO;
-  constexpr int L0 = rb_lds_floats<H0>(), L1 = rb_lds_floats<H1>(), L2 = rb_lds_floats<H2>();
+  constexpr int L0 = rb_lds_floats<H0, NB>(), L1 = rb_lds_floats<H1, NB>(), L2 = rb_lds_floats<H2, NB>();
   __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
@@ -389,22 +395,22 @@ __global__ __launch_bounds__(256, 4) void rb_group_kernel(const ConvGroupArgs g)
   int tx, ty;
   CONV_WG_STAMP(lin, 0);
   if (lin < g.off[1]) {
-    const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), 64) : g.gx[0];
+    const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), 32 * NB) : g.gx[0];
     if (lin >= gx * g.gy[0]) return;
     xcd_tile_lin(lin, gx, g.gy[0], tx, ty);
-    rb_tile<K0, H0>(g.c[0], tx, ty, b, xs);
+    rb_tile<K0, H0, EPI_LINEAR, false, NB>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
-    const int gx = ragged ? row_tiles(conv_n_len<K1, EPI_LINEAR>(g.c[1], b), 64) : g.gx[1];
+    const int gx = ragged ? row_tiles(conv_n_len<K1, EPI_LINEAR>(g.c[1], b), 32 * NB) : g.gx[1];
     if (l >= gx * g.gy[1]) return;
     xcd_tile_lin(l, gx, g.gy[1], tx, ty);
-    rb_tile<K1, H1>(g.c[1], tx, ty, b, xs);
+    rb_tile<K1, H1, EPI_LINEAR, false, NB>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
-    const int gx = ragged ? row_tiles(conv_n_len<K2, EPI_LINEAR>(g.c[2], b), 64) : g.gx[2];
+    const int gx = ragged ? row_tiles(conv_n_len<K2, EPI_LINEAR>(g.c[2], b), 32 * NB) : g.gx[2];
     if (l >= gx * g.gy[2]) return;
     xcd_tile_lin(l, gx, g.gy[2], tx, ty);
-    rb_tile<K2, H2>(g.c[2], tx, ty, b, xs);
+    rb_tile<K2, H2, EPI_LINEAR, false, NB>(g.c[2], tx, ty, b, xs);
   }
   CONV_WG_STAMP(lin, 1);
 }

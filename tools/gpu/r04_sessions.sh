@@ -483,4 +483,13 @@ for f in sorted(glob.glob("gpurun_out/r04_ab14/*.json")):
 PY
 }
 
+diag_stage0_nb1() {
+# the 256-channel stage on the continuous-stream tile with ONE column block per wave (128 rows x 32 columns: 930 workgroups)
+cd $GRAFT_REPO_ROOT
+S0="-DCG_C=256 -DCG_L=4936"
+T0="-DCG_CI=64 -DCG_MB=2 -DCG_NB=1 -DCG_WN=1 -DCG_KS=8 -DCG_WM=1"
+bash tools/gpu/rb_diag.sh r04_diag15 "$S0 $T0" "$S0 -DRB_NEW=1 -DCG_NB=1" "$S0 -DRB_NEW=1 -DCG_NB=1 -DRB_LB=5" "$S0 -DRB_NEW=1 -DCG_NB=2" "$S0 -DRB_NEW=1 -DCG_NB=1 -DRB_ONLY=2" "$S0 $T0 -DRB_ONLY=2" "-DCG_C=128 -DCG_L=39488 -DRB_NEW=1 -DCG_NB=1" > /dev/null
+grep -E "^##|member k|L x8|1 stream|2 stream|4 stream" gpurun_out/r04_diag15/rb_diag.log
+}
+
 "$@"

@@ -108,7 +108,7 @@ constexpr int LDSF = cmax(cmax(conv_lds_floats<11, CG_CI0, CG_MB, CG_NB, CG_WN, 
 #ifndef RB_LB
 #define RB_LB 4
 #endif
-constexpr int LDSF_NEW = cmax(cmax(rb_lds_floats<RbCfg<11>::HALO>(), rb_lds_floats<RbCfg<7>::HALO>()), rb_lds_floats<RbCfg<3>::HALO>());
+constexpr int LDSF_NEW = cmax(cmax(rb_lds_floats<RbCfg<11>::HALO, CG_NB>(), rb_lds_floats<RbCfg<7>::HALO, CG_NB>()), rb_lds_floats<RbCfg<3>::HALO, CG_NB>());
 template <bool NEW>
 __device__ __forceinline__ void run_tile(const ConvGroupArgs& g, int m, int l, float* xs) {
   int tx, ty;
@@ -118,9 +118,9 @@ __device__ __forceinline__ void run_tile(const ConvGroupArgs& g, int m, int l, f
   m = RB_ONLY;
 #endif
   if constexpr (NEW) {
-    if (m == 0) rb_tile<11, RbCfg<11>::HALO>(g.c[0], tx, ty, 0, xs);
-    else if (m == 1) rb_tile<7, RbCfg<7>::HALO>(g.c[1], tx, ty, 0, xs);
-    else rb_tile<3, RbCfg<3>::HALO>(g.c[2], tx, ty, 0, xs);
+    if (m == 0) rb_tile<11, RbCfg<11>::HALO, EPI_LINEAR, false, CG_NB>(g.c[0], tx, ty, 0, xs);
+    else if (m == 1) rb_tile<7, RbCfg<7>::HALO, EPI_LINEAR, false, CG_NB>(g.c[1], tx, ty, 0, xs);
+    else rb_tile<3, RbCfg<3>::HALO, EPI_LINEAR, false, CG_NB>(g.c[2], tx, ty, 0, xs);
     return;
   }
   if (m == 0) conv_tile<11, CG_CI0, CG_MB, CG_NB, CG_WN, CG_KS, 56, EPI_LINEAR, CG_WM>(g.c[0], tx, ty, 0, xs);
@@ -243,7 +243,7 @@ int main(int argc, char** argv) {
   {  // the new tile against the chunked one, bit for bit
     ConvGroupArgs g0, g1; double flop;
     make(CG_L, 0, g0, flop); make(CG_L, 1, g1, flop);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), dim3(g0.off[3]), dim3(256), 0, st[0], g0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3, CG_NB>), dim3(g0.off[3]), dim3(256), 0, st[0], g0);
     hipLaunchKernelGGL(diag_group_kernel<false>, dim3(g1.off[3]), dim3(NTHREADS), 0, st[0], g1, d_ticket);
     CK(hipStreamSynchronize(st[0]));
     std::vector<float> y0((size_t)C * CG_L), y1((size_t)C * CG_L);
