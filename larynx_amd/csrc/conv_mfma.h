@@ -860,11 +860,63 @@ __global__ __launch_bounds__(64 * WM * WN * KS, ((EPI == EPI_LINEAR && ((NB == 1
 // exactly the code of conv_mfma_kernel, so results are bit-identical to three launches.
 // Group sizes are padded to multiples of 8 so a tile's XCD (workgroup id % 8) is the one
 // xcd_tile_lin assumes.
+constexpr int GROUP_MAX_SEG = 8;
 struct ConvGroupArgs {
   ConvArgs c[3];
   int gx[3], gy[3];  // tile grid of each member (x = time tiles, y = row tiles)
   int off[4];        // first workgroup of each member (multiples of 8), off[3] = grid size
+  // Optional dispatch order (rb_group_kernel; group_snake_order below): workgroups [seg_off[s], seg_off[s + 1]) run tiles
+  // seg_first[s] ... of member seg_m[s]; every bound a multiple of 8, so a tile's XCD stays workgroup id % 8.  nseg = 0: the
+  // plain longest-first order of `off`.
+  int nseg = 0;
+  int seg_off[GROUP_MAX_SEG + 1];
+  int seg_first[GROUP_MAX_SEG];
+  int seg_m[GROUP_MAX_SEG];
 };
+
+// A grouped launch whose workgroups are ALL resident at once (<= `slots` = CUs x workgroups per CU) is not balanced by the
+// dispatcher: it deals workgroup i to CU i mod `ncu` (XCD i mod 8, then round-robin over the XCD's CUs — measured, every one of
+// 224 second-round workgroups of a 480-workgroup launch sat on the CU of workgroup i - 256: profiles/NOTES.md), so with the
+// longest-first order the CUs that got an 11-tap tile in the first round get the 7-tap tiles of the second, and the launch
+// lasts 18 tap-units where the mean CU has 12.8.  This lays the rounds out as a snake — round 0 longest first, round 1
+// SHORTEST first, ... — so the CU with the longest tile of one round gets the shortest of the next (14 tap-units for that
+// launch).  Launches with more workgroups than slots keep the plain order (the dispatcher then balances them as slots free).
+inline void group_snake_order(ConvGroupArgs& g, int ncu, int slots) {
+  g.nseg = 0;
+  const int total = g.off[3];
+  if (ncu <= 0 || (ncu & 7) || total <= ncu || total > slots) return;
+  struct Piece { int m, first, n; };
+  Piece out[GROUP_MAX_SEG];
+  int nout = 0;
+  for (int r0 = 0; r0 < total; r0 += ncu) {
+    const int r1 = r0 + ncu < total ? r0 + ncu : total;
+    Piece round[3];
+    int nr = 0;
+    for (int m = 0; m < 3; ++m) {  // the part of member m (workgroups off[m] .. off[m + 1] of the plain order) inside this round
+      const int a = g.off[m] > r0 ? g.off[m] : r0, b = g.off[m + 1] < r1 ? g.off[m + 1] : r1;
+      if (b > a) round[nr++] = Piece{m, a - g.off[m], b - a};
+    }
+    const bool rev = ((r0 / ncu) & 1) != 0;
+    for (int i = 0; i < nr; ++i) {
+      const Piece& pc = round[rev ? nr - 1 - i : i];
+      if (nout && out[nout - 1].m == pc.m && out[nout - 1].first + out[nout - 1].n == pc.first) {
+        out[nout - 1].n += pc.n;
+        continue;
+      }
+      if (nout == GROUP_MAX_SEG) return;  // (cannot happen with three members and <= 4 rounds; keep the plain order)
+      out[nout++] = pc;
+    }
+  }
+  int o = 0;
+  for (int i = 0; i < nout; ++i) {
+    g.seg_off[i] = o;
+    g.seg_first[i] = out[i].first;
+    g.seg_m[i] = out[i].m;
+    o += out[i].n;
+  }
+  g.seg_off[nout] = o;
+  g.nseg = nout;
+}
 template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2, int WM = 1>
 // (second launch bound = waves per SIMD: 4 keeps every member under 128 VGPRs, i.e. two 8-wave workgroups per CU)
 __global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4 || (MB == 1 && NB == 2 && KS == 4)) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {

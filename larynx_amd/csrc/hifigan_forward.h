@@ -362,6 +362,12 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
       for (int d = 0; d < nd; ++d) {
         Step sp[3];
         for (int j = 0; j < nk; ++j) CHECK(plan_step(j, d, sp[j]));
+        if (nk == 3 && !sp[0].pair.ok && !sp[1].pair.ok && !sp[2].pair.ok) {  // tile shape of the step: before the schedule is chosen
+          ConvPlan* c1s[3] = {&sp[0].c1, &sp[1].c1, &sp[2].c1};
+          ConvPlan* c2s[3] = {&sp[0].c2, &sp[1].c2, &sp[2].c2};
+          promote_group_plans(ctx, w, c1s, nk);
+          promote_group_plans(ctx, w, c2s, nk);
+        }
         bool done = false;
         if (grouped) {
           bool all_pair = true, none_pair = true;

@@ -64,6 +64,7 @@ struct Worker {
 
 struct mi355tts_ctx {
   int device = 0;
+  int ncu = 256;  // compute units (hipGetDeviceProperties at create): the dispatch-order logic of grouped launches
   std::mutex mu;
   std::map<int, std::shared_ptr<GlowModel>> glow;
   std::map<int, std::shared_ptr<HifiModel>> hifi;

@@ -128,6 +128,8 @@ struct ConvPlan {
   double flop = 0;
   bool empty = true;
   int bf16 = 0;  // 0 = f32 kernel; 3 = split-bf16 kernel, 1 = plain bf16 kernel (conv_bf16.h); `shape` is then a Bf16Cfg
+  int n_max = 0;        // columns of the implicit GEMM (longest row)
+  bool pinned = false;  // the tile shape was forced (MI355TTS_FORCE_TILE, pin_tile): run_group leaves it alone
 };
 
 // Tile configurations of the split-bf16 kernel (all 4 waves; a wave owns 1 x NB blocks over all input channels)
@@ -274,6 +276,8 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
   out->shape = shape;
   out->epi = epi;
   out->cls = cls;
+  out->n_max = n_max;
+  out->pinned = pinned;
   out->grid = dim3((n_max + T_T - 1) / T_T, ytiles, B);
   out->flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
   out->empty = false;
@@ -386,6 +390,50 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   return 0;
 }
 // Returns 0 = launched as one group, 1 = not groupable (caller launches the members one by one), < 0 = error.
+// a member of a grouped launch the continuous-stream tile (rb_conv.h) covers: a plain ResBlock conv — bias, optional residual
+static bool rb_member_ok(const ConvArgs& a, int K) {
+  const int halo = K == 11 ? RbCfg<11>::HALO : K == 7 ? RbCfg<7>::HALO : RbCfg<3>::HALO;
+  return !a.x2 && !a.x3 && a.bias && a.alpha == 1.0f && !a.accum && a.out_act == ACT_NONE && a.split >= a.rows && !a.y2 &&
+         a.rows % 128 == 0 && (K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= halo;
+}
+
+// CUs of the device as the dispatch-order logic sees them (MI355TTS_GROUP_NCU overrides: tests reach the multi-round shapes at
+// emulator sizes with it)
+static int group_ncu(const mi355tts_ctx* ctx) {
+  if (const char* e = std::getenv("MI355TTS_GROUP_NCU")) return std::atoi(e);
+  return ctx->ncu;
+}
+
+// The same-geometry convs of the three MRF chains of a step (hifigan_forward.h plans them together).  At batch 1, members that
+// plan_conv left on the small tiles (a stage too short for its 128-row threshold: the 256-channel stage of 'high') move to the
+// 128-row tile when together they give every CU more than one workgroup: as ONE grouped launch of the continuous-stream tile
+// with the dispatch laid out as a snake (run_group, group_snake_order) that step runs at 121 us where the 64 x 32 k-split tile
+// needs 133 (one stream; 108 against 124 with two streams in flight — profiles/r04_rb_diag_snake_order.txt).  Decided on the
+// plans, before the schedule is: the forked / one-by-one schedules then run the same tile arithmetic (same bits).
+static void promote_group_plans(mi355tts_ctx* ctx, Worker* w, ConvPlan* const* plans, int n) {
+  // (option "rb_conv" = 0 / MI355TTS_NO_RB_CONV then run the chunked 128-row kernel in the plain order: same bits, slower)
+  static const bool no_promote = [] { const char* e = std::getenv("MI355TTS_NO_GROUP_PROMOTE"); return e && std::atoi(e) != 0; }();
+  (void)w;
+  if (n != 3 || no_promote) return;
+  int total = 0, taps = 0;
+  for (int i = 0; i < 3; ++i) {
+    const ConvPlan& p = *plans[i];
+    if (p.empty || p.bf16 || p.pinned || p.epi != EPI_LINEAR || p.cls != KC_RESBLOCK || p.shape == TILE_M128 || p.grid.z != 1 ||
+        p.n_max <= 0 || (p.a.x_ld % 4) || (p.K != 11 && p.K != 7 && p.K != 3) || !rb_member_ok(p.a, p.K))
+      return;
+    taps |= p.K == 11 ? 1 : p.K == 7 ? 2 : 4;
+    total += (((p.n_max + 63) / 64) * (p.a.rows / 128) + 7) & ~7;
+  }
+  if (taps != 7 || total <= group_ncu(ctx)) return;
+  for (int i = 0; i < 3; ++i) {
+    ConvPlan& p = *plans[i];
+    p.shape = TILE_M128;
+    p.MB = 1;
+    p.a.rows_major = 0;
+    p.grid = dim3((p.n_max + 63) / 64, p.a.rows / 128, 1);
+  }
+}
+
 static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n, hipStream_t s) {
   static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_GROUP"); return e && std::atoi(e) != 0; }();
   if (off || n != 3) return 1;
@@ -394,6 +442,8 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   for (int i = 0; i < 3; ++i)
     for (int j = i + 1; j < 3; ++j)
       if (plans[ord[j]].K > plans[ord[i]].K) std::swap(ord[i], ord[j]);
+  static const bool rb_off = [] { const char* e = std::getenv("MI355TTS_NO_RB_CONV"); return e && std::atoi(e) != 0; }();
+  const int ncu = group_ncu(ctx);
   const ConvPlan& p0 = plans[ord[0]];
   for (int i = 0; i < 3; ++i) {
     const ConvPlan& p = plans[ord[i]];
@@ -454,16 +504,12 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   ProfScope ps(ctx, w, p0.cls, flop, s);
   // The 128-row tile with the continuous matrix stream (rb_conv.h; same bits as the chunked tile) where the launch is
   // what it was written for: plain ResBlock convs (bias, optional residual), taps 11 / 7 / 3, dilation within its halos.
-  static const bool rb_off = [] { const char* e = std::getenv("MI355TTS_NO_RB_CONV"); return e && std::atoi(e) != 0; }();
   if (p0.shape == TILE_M128 && k0 == 11 && !rb_off && w->o_rb_conv) {
     bool rb_ok = true;
-    for (int i = 0; i < 3; ++i) {
-      const ConvArgs& a = g.c[i];
-      const int K = i == 0 ? 11 : i == 1 ? 7 : 3, halo = i == 0 ? RbCfg<11>::HALO : i == 1 ? RbCfg<7>::HALO : RbCfg<3>::HALO;
-      rb_ok = rb_ok && !a.x2 && !a.x3 && a.bias && a.alpha == 1.0f && !a.accum && a.out_act == ACT_NONE && a.split >= a.rows && !a.y2 &&
-              a.rows % 128 == 0 && (K - 1) * a.dil + ((4 - a.pad % 4) % 4) <= halo;
-    }
+    for (int i = 0; i < 3; ++i) rb_ok = rb_ok && rb_member_ok(g.c[i], i == 0 ? 11 : i == 1 ? 7 : 3);
     if (rb_ok) {
+      static const bool no_snake = [] { const char* e = std::getenv("MI355TTS_NO_SNAKE"); return e && std::atoi(e) != 0; }();
+      if (grid.z == 1 && !no_snake) group_snake_order(g, ncu, 4 * ncu);  // four of these workgroups fit a CU (32 KB, <= 128 VGPRs)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), grid, dim3(256), 0, s, g);
       return 0;
     }

@@ -55,6 +55,10 @@ extern "C" int mi355tts_create(int device, mi355tts_ctx** out) {
   HIPCHECK(hipSetDevice(device));
   mi355tts_ctx* c = new mi355tts_ctx();
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
+  }
   *out = c;
   return 0;
 }

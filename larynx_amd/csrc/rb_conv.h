@@ -26,6 +26,9 @@ namespace mi355tts {
 #ifndef RB_PRIO  // wave priority outside the main loop (prologue / epilogue of a tile that starts among running ones)
 #define RB_PRIO 3
 #endif
+#ifndef RB_WIDE_STORES  // interior tiles store 16 bytes per lane after a transpose through LDS (0 = A/B builds: dword stores)
+#define RB_WIDE_STORES 1
+#endif
 #ifndef RB_ABL  // probe builds only (tools/probe/rb_diag.hip; results are WRONG when set): ablation bit mask
 #define RB_ABL 0
 #endif
@@ -309,7 +312,44 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
   float bb[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bb[r] = (RB_ABL & 16) ? 0.01f : a.bias[row0 + (r & 3) + 8 * (r >> 2)];  // packed bias: padded to whole m-tiles, never null here
-  if (interior) {
+  if (interior && NB == 2 && RB_WIDE_STORES && (a.y_ld & 3) == 0) {
+    // Interior tiles: the accumulator blocks go through LDS once ([32 rows][64 columns] per wave, over the dead ring) so that
+    // a lane holds FOUR consecutive columns: 8 dwordx4 residual loads + 8 dwordx4 stores per lane instead of 32 + 32 dword ones
+    // (the epilogue of such a tile is store-ISSUE-bound: MI355X_MICROARCH.md).  Same arithmetic: (acc + bias) + residual.
+    __syncthreads();  // every wave has issued its last operand read of the ring
+    float* tw = xs + wm * (32 * 64);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + rbase) * 64 + nb * 32 + col] = acc[nb][r] + bb[r];
+    __builtin_amdgcn_wave_barrier();  // no instruction: LDS operations of one wave execute in order, its reads below see its writes
+    const int rbase0 = mt0 * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 v[4], rv[4];
+      int off[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * (4 * h + i);
+        const int row = idx >> 4, c4 = idx & 15;
+        off[i] = (rbase0 + row) * a.y_ld + t0 + 4 * c4;
+        v[i] = *reinterpret_cast<const float4*>(tw + row * 64 + 4 * c4);
+      }
+      if (rb && !(RB_ABL & 16)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rv[i] = *reinterpret_cast<const float4*>(rb + off[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i].x += rv[i].x;
+          v[i].y += rv[i].y;
+          v[i].z += rv[i].z;
+          v[i].w += rv[i].w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(yb + off[i]) = v[i];
+    }
+  } else if (interior) {
     const int o0 = row0 * a.y_ld + t0 + col;  // a plane of one batch row is < 2^31 floats (conv_tile indexes it the same way)
     if (rb && !(RB_ABL & 16)) {  // one batch of residual loads per column block (the first goes out together with the bias loads)
 #pragma unroll
@@ -394,19 +434,27 @@ __global__ __launch_bounds__(256, 4) void rb_group_kernel(const ConvGroupArgs g)
   const bool ragged = gridDim.z > 1;
   int tx, ty;
   CONV_WG_STAMP(lin, 0);
-  if (lin < g.off[1]) {
+  int m, l;  // member and tile of this workgroup
+  if (g.nseg) {  // the host's dispatch order (group_snake_order)
+    int sg = 0;
+    while (sg + 1 < g.nseg && lin >= g.seg_off[sg + 1]) ++sg;
+    m = g.seg_m[sg];
+    l = g.seg_first[sg] + (lin - g.seg_off[sg]);
+  } else {
+    m = lin < g.off[1] ? 0 : lin < g.off[2] ? 1 : 2;
+    l = lin - g.off[m];
+  }
+  if (m == 0) {
     const int gx = ragged ? row_tiles(conv_n_len<K0, EPI_LINEAR>(g.c[0], b), 32 * NB) : g.gx[0];
-    if (lin >= gx * g.gy[0]) return;
-    xcd_tile_lin(lin, gx, g.gy[0], tx, ty);
+    if (l >= gx * g.gy[0]) return;
+    xcd_tile_lin(l, gx, g.gy[0], tx, ty);
     rb_tile<K0, H0, EPI_LINEAR, false, NB>(g.c[0], tx, ty, b, xs);
-  } else if (lin < g.off[2]) {
-    const int l = lin - g.off[1];
+  } else if (m == 1) {
     const int gx = ragged ? row_tiles(conv_n_len<K1, EPI_LINEAR>(g.c[1], b), 32 * NB) : g.gx[1];
     if (l >= gx * g.gy[1]) return;
     xcd_tile_lin(l, gx, g.gy[1], tx, ty);
     rb_tile<K1, H1, EPI_LINEAR, false, NB>(g.c[1], tx, ty, b, xs);
   } else {
-    const int l = lin - g.off[2];
     const int gx = ragged ? row_tiles(conv_n_len<K2, EPI_LINEAR>(g.c[2], b), 32 * NB) : g.gx[2];
     if (l >= gx * g.gy[2]) return;
     xcd_tile_lin(l, gx, g.gy[2], tx, ty);

@@ -24,6 +24,9 @@
 #ifndef RBP_PREFETCH32
 #define RBP_PREFETCH32 0
 #endif
+#ifndef RBP_WIDE_STORES  // interior tiles: accumulators transposed through LDS, 16-byte residual loads and stores (rb_conv.h)
+#define RBP_WIDE_STORES 1
+#endif
 #ifndef RBP_LB32  // waves per SIMD the C = 32 kernel is compiled for: 3 (132 VGPRs, no spills; measured 129.8 us per grouped
 #define RBP_LB32 3  // launch) or 4 (four 40 KB workgroups per CU, 3 spilled registers: 132.1 us)
 #endif
@@ -205,9 +208,74 @@ __device__ __forceinline__ void rbp_tile(const PairArgs& a, const int tile_x, co
       for (int r = 0; r < 16; ++r) rv[nb][r] = xb[(mb * 32 + (r & 3) + 8 * (r >> 2) + rbase) * a.ld + gcs[nb]];
   };
   constexpr bool PREFETCH = CB == 2 ? (RBP_PREFETCH64 != 0) : (RBP_PREFETCH32 != 0);
+  const bool interior = RBP_WIDE_STORES && !PREFETCH && j0 + T1 <= L;  // uniform: every column of the tile is inside the sequence
   if (PREFETCH) epi_loads();
   zero_acc();
   rbp_phase<K, NOCT>(acc, wq2, xs + half * TW + wcol0 + col, TW, 1);
+  if (interior) {
+    // The accumulator blocks go through LDS once ([32 rows][64 columns] per wave, over the dead parked tile) so that a lane
+    // holds FOUR consecutive columns: 8 16-byte residual loads + 8 16-byte stores per lane instead of 32 + 32 dword ones.  A
+    // tile starts at column tile_x * T2, so these are dword-aligned 16-byte accesses (global memory takes them).  Same
+    // arithmetic, same order: ((acc + bias) + x) * alpha [+ y].
+    typedef float rbp_f4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb2[r] = a.b2[mb * 32 + (r & 3) + 8 * (r >> 2) + rbase];
+    __syncthreads();  // every wave has read its last parked column
+    float* tw = xs + wave * (32 * 64);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + rbase) * 64 + nb * 32 + col] = acc[nb][r] + bb2[r];
+    __builtin_amdgcn_wave_barrier();  // no instruction: a wave's LDS operations execute in order
+    float* yb = a.y + (long long)b * a.bs;
+    const float alpha = a.alpha;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 v[4];
+      rbp_f4 rx[4];
+      int off[4], jjs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * (4 * h + i);
+        const int row = idx >> 4, c4 = idx & 15;
+        jjs[i] = wcol0 + 4 * c4;
+        off[i] = (mb * 32 + row) * a.ld + j0 + jjs[i];
+        v[i] = *reinterpret_cast<const float4*>(tw + row * 64 + 4 * c4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rx[i] = *reinterpret_cast<const rbp_f4*>(xb + off[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i].x = (v[i].x + rx[i].x) * alpha;
+        v[i].y = (v[i].y + rx[i].y) * alpha;
+        v[i].z = (v[i].z + rx[i].z) * alpha;
+        v[i].w = (v[i].w + rx[i].w) * alpha;
+      }
+      if (a.accum) {
+        rbp_f4 ov[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const rbp_f4*>(yb + off[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i].x += ov[i].x;
+          v[i].y += ov[i].y;
+          v[i].z += ov[i].z;
+          v[i].w += ov[i].w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (jjs[i] + 3 < T2) {
+          *reinterpret_cast<rbp_f4*>(yb + off[i]) = rbp_f4{v[i].x, v[i].y, v[i].z, v[i].w};
+        } else {  // the tile's last columns (T2 is not a multiple of four)
+          if (jjs[i] < T2) yb[off[i]] = v[i].x;
+          if (jjs[i] + 1 < T2) yb[off[i] + 1] = v[i].y;
+          if (jjs[i] + 2 < T2) yb[off[i] + 2] = v[i].z;
+        }
+      }
+    }
+    return;
+  }
   if (!PREFETCH) epi_loads();
   // ---- epilogue: + bias + residual
 #pragma unroll

@@ -269,6 +269,8 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// lanes are fibers here: a wave's lock step (an LDS write another lane of the SAME wave then reads) needs a real rendezvous
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 // only ever applied to wave-uniform values in csrc/ (it tells the compiler they ARE uniform)
 #define __builtin_amdgcn_readfirstlane(x) (x)

@@ -391,6 +391,55 @@ def test_continuous_stream_tile_equals_the_chunked_tile(emu_engine, monkeypatch)
         emu_engine.unload(v)
 
 
+def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
+    """At batch 1 the same-geometry ResBlock convs of a step that plan_conv left on the small tiles move to the 128-row tile
+    when together they give every CU more than one workgroup (`promote_group_plans`, decided on the plans: every schedule then
+    runs the same tile arithmetic), and a grouped launch whose workgroups are all resident at once is dispatched as a snake
+    (`group_snake_order`: round 0 longest first, round 1 shortest first).  `MI355TTS_GROUP_NCU` = 24 makes the 300-frame shape
+    such a launch (16 + 16 + 16 workgroups in rounds of 24: segments k11 x16, k7 x8, k3 x16, k7 x8).  The order is a
+    permutation of the tiles: same bits as the chunked 128-row kernel in its plain order (option rb_conv = 0), as the forked
+    schedule, and as the plain order of the same kernel."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 5), (1, 3), (1, 5)), num_mels=16)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=95)
+    v = emu_engine.load_hifigan(hp, sd)
+    rng = np.random.default_rng(14)
+    try:
+        mel = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 300))).astype(np.float32)
+        mb = emu_engine.mel_from_numpy(mel)
+        monkeypatch.setenv("MI355TTS_GROUP_NCU", "24")
+        emu_engine.set_profiling(True)
+        emu_engine.profile_reset()
+        promoted, _ = emu_engine.hifigan_infer(v, mb)  # small tiles in the plan -> promoted, snake order
+        n_grouped = emu_engine.profile()["conv_mfma.hifigan_resblock"]["launches"]
+        emu_engine.set_profiling(False)
+        emu_engine.set_option("rb_conv", 0)
+        try:
+            chunked, _ = emu_engine.hifigan_infer(v, mb)  # promoted too; the chunked 128-row kernel, plain order
+        finally:
+            emu_engine.set_option("rb_conv", 1)
+        emu_engine.set_option("mrf_group", 0)
+        try:
+            forked, _ = emu_engine.hifigan_infer(v, mb)   # promoted; one launch per conv
+        finally:
+            emu_engine.set_option("mrf_group", 1)
+        monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
+        monkeypatch.setenv("MI355TTS_GROUP_NCU", "8")     # 48 workgroups > 4 x 8: the plain order of the same kernel
+        plain, _ = emu_engine.hifigan_infer(v, mb)
+        monkeypatch.delenv("MI355TTS_M128_MIN_TILES")
+        monkeypatch.setenv("MI355TTS_GROUP_NCU", "1024")  # no step has more workgroups than CUs: no promotion, the 64 x 32 k-split tile
+        small, _ = emu_engine.hifigan_infer(v, mb)
+        assert np.isfinite(promoted).all() and np.abs(promoted).max() > 1e-3
+        assert n_grouped == 2 * 2 + 2  # the 128-channel stage: two grouped launches per dilation step; the 64-channel stage: fused pairs
+        assert np.array_equal(promoted, chunked) and np.array_equal(promoted, forked)
+        # (MI355TTS_M128_MIN_TILES also moves the upsamplers to their 128-row tile — another summation order: round-off here)
+        assert np.abs(plain - promoted).max() <= 1e-6
+        assert not np.array_equal(small, promoted) and np.abs(small - promoted).max() <= 1e-6  # the k-split tile sums in another order
+    finally:
+        emu_engine.set_profiling(False)
+        emu_engine.unload(v)
+
+
 def test_four_wave_pair_kernel_against_the_k_split_one(emu_engine, monkeypatch):
     """`rb_pair_kernel` / `rb_pair_group_kernel` (rb_pair.h: 4 waves, no k-split, the parked conv1 tile over the x tile) run the
     fused ResBlock steps of the 64- / 32-channel stages by default; option "rb_pair" = 0 sends them to the 8-wave k-split

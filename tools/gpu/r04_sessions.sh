@@ -492,4 +492,76 @@ bash tools/gpu/rb_diag.sh r04_diag15 "$S0 $T0" "$S0 -DRB_NEW=1 -DCG_NB=1" "$S0 -
 grep -E "^##|member k|L x8|1 stream|2 stream|4 stream" gpurun_out/r04_diag15/rb_diag.log
 }
 
+
+ab_wide_stores() {
+# interior tiles of rb_conv.h / rb_pair.h store 16 bytes per lane after a transpose through LDS (-DRB_WIDE_STORES / -DRBP_WIDE_STORES,
+# default 1).  Three builds: _nowide (both 0), _rbwide (rb_conv.h only), default (both).  Bits, kernel stats, bench, parity.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab15; mkdir -p $O
+for q in high medium; do PYTHONPATH=. python tools/ab_bits.py larynx_amd/libmi355tts_nowide.so larynx_amd/libmi355tts.so $q; done
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in _nowide _rbwide ""; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/t$v -o t --output-format csv -- $B --library larynx_amd/libmi355tts$v.so > $O/t$v.log 2>&1
+  f=$(find $O/t$v -name "*kernel_stats.csv" | head -1)
+  echo "== lib$v"; grep -E "rb_|conv_group|conv_kernel" $f | cut -c1-150
+  rm -rf $O/t$v
+done
+B2="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode"
+for i in 1 2; do for v in _nowide _rbwide ""; do timeout 300 $B2 --library larynx_amd/libmi355tts$v.so > $O/lib${v}_$i.json 2> $O/lib${v}_$i.err; done; done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab15/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); p = j["profile_ms_per_step"]
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "steady %.1f" % j["steady_state"]["utterances_per_sec"], "lat %.3f" % j["latency_ms_single_stream"], "frac %.4f" % j["roofline"]["frac"], "resblock %.3f" % p["conv_mfma.hifigan_resblock"])
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
+}
+
+ab_wide_stores_inproc() {
+# the same three builds alternating inside ONE process (tools/ab_inproc.py): single-stream and four caller threads
+cd $GRAFT_REPO_ROOT
+L="larynx_amd/libmi355tts_nowide.so larynx_amd/libmi355tts_rbwide.so larynx_amd/libmi355tts.so"
+PYTHONPATH=. timeout 400 python tools/ab_inproc.py --streams 1 $L
+PYTHONPATH=. timeout 400 python tools/ab_inproc.py --streams 4 --calls 10 $L
+PYTHONPATH=. timeout 400 python tools/ab_inproc.py --streams 1 $L
+}
+
+diag_snake_order() {
+# the 256-channel stage on the continuous-stream tile (128 x 64, 468 workgroups at 624 frames: all resident at once) with the
+# rounds of the dispatch laid out as a snake (group_snake_order, conv_mfma.h) instead of longest-first; 1200 frames too
+cd $GRAFT_REPO_ROOT
+S0="-DCG_C=256 -DCG_L=4992"; S1="-DCG_C=256 -DCG_L=9600"
+T0="-DCG_CI=64 -DCG_MB=2 -DCG_NB=1 -DCG_WN=1 -DCG_KS=8 -DCG_WM=1"
+bash tools/gpu/rb_diag.sh r04_diag18 "$S0 $T0" "$S0 -DRB_NEW=1 -DCG_NB=2" "$S0 -DRB_NEW=1 -DCG_NB=2 -DRB_ORDER=2" "$S1 $T0" "$S1 -DRB_NEW=1 -DCG_NB=2" "$S1 -DRB_NEW=1 -DCG_NB=2 -DRB_ORDER=2" > /dev/null
+grep -E "^##|member k|L x8|1 stream|2 stream|4 stream" gpurun_out/r04_diag18/rb_diag.log
+}
+
+ab_snake() {
+# the 256-channel stage promoted to the continuous-stream tile with the snake dispatch order (run_group / group_snake_order)
+# against the 64 x 32 k-split tile (MI355TTS_NO_GROUP_PROMOTE=1): kernel stats, bench, parity
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab16; mkdir -p $O
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in old new; do
+  e=0; [ $v = old ] && e=1
+  MI355TTS_NO_GROUP_PROMOTE=$e timeout 300 rocprofv3 --kernel-trace --stats -d $O/t_$v -o t --output-format csv -- $B > $O/t_$v.log 2>&1
+  f=$(find $O/t_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; grep -E "rb_|conv_group|pair" $f | cut -c1-150
+  rm -rf $O/t_$v
+done
+B2="python bench.py --no-cpu-baseline --no-config3 --no-config5 --no-half-mode"
+for i in 1 2; do
+  MI355TTS_NO_GROUP_PROMOTE=1 timeout 300 $B2 > $O/old_$i.json 2> $O/old_$i.err
+  timeout 300 $B2 > $O/new_$i.json 2> $O/new_$i.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab16/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); p = j["profile_ms_per_step"]
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "steady %.1f" % j["steady_state"]["utterances_per_sec"], "lat %.3f" % j["latency_ms_single_stream"], "frac %.4f" % j["roofline"]["frac"],
+          "resblock %.3f" % p["conv_mfma.hifigan_resblock"], "config4 %.0f (%.3f ms single)" % (j["config4"]["utterances_per_sec"], j["config4"]["latency_ms_single_stream"]))
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
+}
+
 "$@"

@@ -3,7 +3,8 @@
 //   * S concurrent streams of the same launch (does the hardware fill one launch's tail with the next launch's head?),
 //   * a per-workgroup timeline (begin / end in s_memrealtime and s_memtime ticks, HW_ID, XCC_ID) dumped to a file,
 //   * per-chunk phase stamps of sampled workgroups (-DRB_CHUNK_STAMPS),
-//   * dispatch-order variants: -DRB_ORDER=1 interleaves the three members in runs of 8 workgroups, -DRB_PERSIST=1 runs
+//   * dispatch-order variants: -DRB_ORDER=1 interleaves the three members in runs of 8 workgroups, -DRB_ORDER=2 is the
+//     product's snake order for all-resident launches (group_snake_order), -DRB_PERSIST=1 runs
 //     the tiles from an atomic ticket counter on a grid of RB_PERSIST_WGS workgroups.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DCG_C=128 -DCG_L=39488 -DCG_CI=16 ... ] tools/probe/rb_diag.hip -o /tmp/rbd
 // Run:   /tmp/rbd [dump-file]
@@ -171,8 +172,17 @@ __global__ __launch_bounds__(NEW ? 256 : NTHREADS, NEW ? RB_LB : CG_LB) void dia
   const int run = lin >> 3, m = run % 3;
   run_tile<NEW>(g, m, (run / 3) * 8 + (lin & 7), xs);
 #else
-  const int m = lin < g.off[1] ? 0 : lin < g.off[2] ? 1 : 2;
-  run_tile<NEW>(g, m, lin - g.off[m], xs);
+  int m, l;
+  if (g.nseg) {  // -DRB_ORDER=2: the product's snake order (group_snake_order, conv_mfma.h)
+    int sg = 0;
+    while (sg + 1 < g.nseg && lin >= g.seg_off[sg + 1]) ++sg;
+    m = g.seg_m[sg];
+    l = g.seg_first[sg] + (lin - g.seg_off[sg]);
+  } else {
+    m = lin < g.off[1] ? 0 : lin < g.off[2] ? 1 : 2;
+    l = lin - g.off[m];
+  }
+  run_tile<NEW>(g, m, l, xs);
 #endif
   CONV_WG_STAMP(lin, 1);
 #endif
@@ -226,6 +236,9 @@ int main(int argc, char** argv) {
       flop += 2.0 * C * C * (RB_ONLY >= 0 ? Ks[RB_ONLY] : K) * (double)L;
     }
     g.off[3] = off;
+#if RB_ORDER == 2
+    group_snake_order(g, 256, 1024);
+#endif
   };
   int* d_ticket;
   CK(hipMalloc(&d_ticket, 4 * 64));
@@ -448,6 +461,7 @@ int main(int argc, char** argv) {
           const WgRec& r = rec[i];
           if (!r.real1) continue;
           int m = i < g.off[1] ? 0 : i < g.off[2] ? 1 : 2;
+          if (g.nseg) { int sg = 0; while (sg + 1 < g.nseg && i >= g.seg_off[sg + 1]) ++sg; m = g.seg_m[sg]; }
 #if RB_ORDER == 1
           m = (i >> 3) % 3;
 #endif
