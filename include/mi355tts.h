@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MI355TTS_ABI_VERSION 1
+#define MI355TTS_ABI_VERSION 2 /* 2: n_speakers / gin_channels in mi355tts_glow_hparams, the *_speakers entry points */
 
 typedef enum {
   MI355TTS_OK = 0,
@@ -54,6 +54,9 @@ typedef struct {
   int32_t dilation_rate, kernel_size_dec, n_block_layers, n_sqz;
   int32_t prenet, window_size, n_split, mel_channels;
   int32_t prenet_kernel_size, prenet_layers; /* glow_tts/models.py:96-97 (5, 3) */
+  /* multi-speaker voices (glow_tts/config.py:56,60; models.py:304-306): n_speakers > 1 with gin_channels in [1, 1024], or a
+   * single-speaker voice: n_speakers <= 1 and gin_channels = 0 */
+  int32_t n_speakers, gin_channels;
 } mi355tts_glow_hparams;
 
 /* hifi_gan/config.py:29-41 (ModelConfig) */
@@ -148,6 +151,19 @@ int mi355tts_glow_infer_rows(mi355tts_ctx* ctx, int glow, const int64_t* ids, co
                              float noise_scale, float length_scale, const uint64_t* row_seeds,
                              const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out);
 
+/* Multi-speaker voices: the reference's `speaker_id` setting (larynx/glow_tts.py:116-130 -> `g` of
+ * FlowGenerator.forward, glow_tts/models.py:318-319: g = F.normalize(emb_g(speaker)), which conditions every WaveNet
+ * layer of the decoder, layers.py:141-154, and is concatenated to the duration predictor's input, models.py:128-132).
+ * `speaker_ids` (host array [B], one speaker per row, each in [0, n_speakers)) is REQUIRED for a model loaded with
+ * n_speakers > 1 and must be NULL for a single-speaker model — the reference fails on both mismatches too (no emb_g /
+ * a duration predictor that expects hidden + gin input channels).  mi355tts_glow_infer / _rows / mi355tts_synthesize on
+ * a multi-speaker model return MI355TTS_ERR_INVALID.  Everything else as in mi355tts_glow_infer; `row_seeds` (optional,
+ * host [B]) as in mi355tts_glow_infer_rows (then `seed` is ignored). */
+int mi355tts_glow_infer_speakers(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                 float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                                 const uint64_t* row_seeds, const int32_t* speaker_ids, const mi355tts_audio_settings* audio,
+                                 uint32_t flags, mi355tts_mel** out);
+
 int mi355tts_mel_batch(const mi355tts_mel* mel);
 int mi355tts_mel_channels(const mi355tts_mel* mel);
 int mi355tts_mel_max_frames(const mi355tts_mel* mel);
@@ -192,6 +208,13 @@ int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t*
                         const mi355tts_audio_settings* audio, float denoiser_strength, int32_t pad_before,
                         int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16, int64_t wav_ld,
                         uint32_t flags);
+
+/* mi355tts_synthesize for a multi-speaker voice: `speaker_ids` as in mi355tts_glow_infer_speakers. */
+int mi355tts_synthesize_speakers(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
+                                 int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld,
+                                 uint64_t seed, const int32_t* speaker_ids, const mi355tts_audio_settings* audio,
+                                 float denoiser_strength, int32_t pad_before, int32_t pad_after, int32_t* frames_out,
+                                 float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags);
 
 /* Serving set-up (the reference warms its model caches the same way, larynx/__init__.py:290,412):
  * pre-create `workers` per-call workers (stream, side streams, pinned staging) and size

@@ -104,6 +104,10 @@ struct ConvArgs {
   int half;
   // EPI_COUPLING only, optional: InvConvNear (pre-inverted 4x4, n_split = 4) + ActNorm
   // reverse fused behind the coupling — z0 = first-half rows of the same tensor
+  // EPI_GATE, multi-speaker voices: row b's speaker offsets of this layer (cond_layer(g) slice, layers.py:141-154), [2 half]
+  // (tanh rows, then sigmoid rows) at cond + b * cond_bs; nullptr = none
+  const float* cond;
+  long long cond_bs;
   float* mix_x0;           // base of the flow tensor (first half), geometry of y
   const float* mix_w;      // [4][4] inverse weight
   const float* mix_bias;   // [2*half] ActNorm bias
@@ -668,6 +672,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile_x, c
       b1[rr] = a.bias ? a.bias[mt0 * 32 + 16 + i] : 0.f;
       const int c = tile_y * 16 + i;
       cok[rr] = c < a.half;
+      if (a.cond) {  // x_in + g_l (layers.py:154): the speaker's offsets of this layer
+        const float* cd = a.cond + (long long)b * a.cond_bs + (cok[rr] ? c : a.half - 1);
+        b0[rr] += cd[0];
+        b1[rr] += cd[a.half];
+      }
       off[rr] = (cok[rr] ? c : a.half - 1) * a.y_ld;
     }
 #pragma unroll

@@ -53,6 +53,8 @@ struct Gate16Args {
   float* y;  // [B][half][y_ld]
   long long y_bs;
   int y_ld;
+  const float* cond;  // multi-speaker voices: this layer's speaker offsets of row b, [2 half], at cond + b * cond_bs (nullptr: none)
+  long long cond_bs;
 };
 
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J)
@@ -155,6 +157,11 @@ __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
       v1 += xs[g * 512 + src + 32];  // row i + 8: two 16-lane groups further
     }
     const int c = ty * 8 + i, t = t0 + n;
+    if (a.cond) {  // x_in + g_l (layers.py:154)
+      const float* cd = a.cond + (long long)b * a.cond_bs + (c < a.half ? c : a.half - 1);
+      v0 += cd[0];
+      v1 += cd[a.half];
+    }
     if (c < a.half && t < L) a.y[(long long)b * a.y_bs + (long long)c * a.y_ld + t] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
   }
   GATE_STAMP(4);

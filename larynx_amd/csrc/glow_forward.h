@@ -104,6 +104,7 @@ struct GlowCall {
   int noise_ld = 0;
   uint64_t seed = 0;
   const uint64_t* row_seeds = nullptr;  // optional, host, [B]: the noise stream of row b (default seed + b)
+  const int32_t* speaker_ids = nullptr;  // host, [B]: multi-speaker voices only (required there, forbidden otherwise)
   // optional, host, [B]: row b's ids live at row_ids[b] (id_lens[b] of them; host or device per `flags`) instead of
   // ids + b * ids_ld — the rows of a coalesced pass come from different callers (host_join.h)
   const int64_t* const* row_ids = nullptr;
@@ -126,6 +127,15 @@ static int find_glow(mi355tts_ctx* ctx, int glow, std::shared_ptr<GlowModel>* ou
 static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) {
   if ((!c.ids && !c.row_ids) || !c.id_lens) return fail(MI355TTS_ERR_INVALID, "null argument");
   if (c.B <= 0 || c.ids_ld <= 0) return fail(MI355TTS_ERR_INVALID, "empty batch");
+  // the reference fails on either mismatch (no emb_g to index / a duration predictor built for hidden + gin channels)
+  if (gm->gin() && !c.speaker_ids)
+    return fail(MI355TTS_ERR_INVALID, "this voice has %d speakers: pass speaker ids (mi355tts_glow_infer_speakers / mi355tts_synthesize_speakers)",
+                gm->hp.n_speakers);
+  if (!gm->gin() && c.speaker_ids) return fail(MI355TTS_ERR_INVALID, "speaker ids given to a single-speaker voice");
+  if (c.speaker_ids)
+    for (int b = 0; b < c.B; ++b)
+      if (c.speaker_ids[b] < 0 || c.speaker_ids[b] >= gm->hp.n_speakers)  // nn.Embedding raises on an out-of-range index
+        return fail(MI355TTS_ERR_INVALID, "speaker_ids[%d]=%d outside [0,%d)", b, c.speaker_ids[b], gm->hp.n_speakers);
   int Pmax = 0;
   for (int b = 0; b < c.B; ++b) {
     if (c.id_lens[b] < 1 || c.id_lens[b] > c.ids_ld)
@@ -148,7 +158,7 @@ static int glow_precheck(const GlowModel* gm, const GlowCall& c, int* Pmax_out) 
 
 // Encoder workspace of one call: ONE definition for the forward pass and mi355tts_reserve.
 struct GlowEncLayout {
-  size_t o_len, o_seed, o_ids, o_x, o_t1, o_t2, o_qkv, o_ffn, o_xm, o_logw, o_cum, o_sc, total;
+  size_t o_len, o_seed, o_ids, o_x, o_t1, o_t2, o_qkv, o_ffn, o_xm, o_logw, o_cum, o_sc, o_spk, o_cond, o_dps, total;
   int P, att_rows;
 };
 static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int ids_ld, int Pmax) {
@@ -171,6 +181,12 @@ static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int 
   L.att_rows = ((Pmax + ATT_ROWS - 1) / ATT_ROWS) * ATT_ROWS;
   // score scratch: only the VALU attention fallback (P > ATTM_MAXP) uses it
   L.o_sc = cv.take(Pmax > ATTM_MAXP ? sizeof(float) * (size_t)B * h.n_heads * L.att_rows * P : 0);
+  // multi-speaker voices: speaker ids, the decoder's gate offsets [B][n_blocks][2H n_layers] (live until the last flow block:
+  // the encoder region is kept when the decoder's is appended) and the duration predictor's per-tap speaker sums [B][Fd][k]
+  const bool spk = h.n_speakers > 1;
+  L.o_spk = cv.take(spk ? sizeof(int) * B : 0);
+  L.o_cond = cv.take(spk ? sizeof(float) * (size_t)B * h.n_blocks_dec * 2 * H * h.n_block_layers : 0);
+  L.o_dps = cv.take(spk ? sizeof(float) * (size_t)B * Fd * h.kernel_size : 0);
   L.total = cv.pos;
   return L;
 }
@@ -259,6 +275,18 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     HIPCHECK(hipMemcpyAsync(d_ids, ids, sizeof(long long) * (size_t)B * ids_ld, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   }
 
+  // multi-speaker voices: everything the speaker vector feeds, once per call (small_kernels.h: speaker_cond_kernel)
+  const int gin = gm->gin();
+  const int n2 = 2 * H * h.n_block_layers;  // gate offsets per flow block
+  float* spk_cond = gin ? (float*)(base + el.o_cond) : nullptr;
+  float* spk_dps = gin ? (float*)(base + el.o_dps) : nullptr;
+  if (gin) {
+    int* d_spk = (int*)(base + el.o_spk);
+    HIPCHECK(hipMemcpyAsync(d_spk, call.speaker_ids, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    ProfScope ps(ctx, w, KC_SMALL, 0);
+    hipLaunchKernelGGL(speaker_cond_kernel, dim3(h.n_blocks_dec + 1, B), dim3(256), 0, s, A + gm->emb_g, h.n_speakers, gin, d_spk,
+                       A + gm->cond_w, A + gm->cond_b, h.n_blocks_dec, n2, spk_cond, A + gm->dp_wg, Fd * k, k, spk_dps);
+  }
   const long long bsH = (long long)H * P;
   {
     ProfScope ps(ctx, w, KC_SMALL, 0);
@@ -361,6 +389,13 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     const long long bsD = (long long)Fd * P;
     ConvArgs c1 = base_args(x, bsH, P, d_len, 1, d1, bsD, P, d_len, 1, 1, k / 2);
     c1.out_act = ACT_RELU;
+    if (gin) {
+      // conv_1 over [x ; g repeated along time] (models.py:128-132) = conv_1's encoder half over x + a plane that depends only
+      // on the speaker and on where the row's zero padding starts: d3 is free until conv_2's fallback may use it
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      hipLaunchKernelGGL(speaker_dp_plane_kernel, dim3((P + 255) / 256, Fd, B), dim3(256), 0, s, spk_dps, Fd, k, k / 2, d_len, d3, bsD, P);
+      c1.res = d3;
+    }
     CHECK(launch_enc_conv(ctx, w, gm, gm->dp1, c1, B, Pmax, glow_tiles, enc_host_len, call.solo_tiles));
     // norm_1 inside conv_2 (launch_ln_conv): d1 -> d2; d3 is the fallback's scratch
     ConvArgs c2 = base_args(d1, bsD, P, d_len, 1, d2, bsD, P, d_len, 1, 1, k / 2);
@@ -462,6 +497,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     if (d_seeds) d_seeds = (unsigned long long*)(base + el.o_seed);
     xm = (float*)(base + o_xm);
     cum = (int*)(base + o_cum);
+    if (gin) spk_cond = (float*)(base + el.o_cond);
   }
   float* z = (float*)(base + o_z);
   float* hbuf = (float*)(base + o_h);
@@ -503,6 +539,10 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
       const int kd = h.kernel_size_dec;
       ConvArgs a = base_args(hbuf, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
       a.half = H;
+      if (gin) {  // x_in + g_l (layers.py:144-154): this block's, this layer's [2H] slice of cond_layer(g), per batch row
+        a.cond = spk_cond + (size_t)blk * n2 + (size_t)j * 2 * H;
+        a.cond_bs = (long long)h.n_blocks_dec * n2;
+      }
       if (B == 1 && dec_host_len >= 0) {  // the length is known on the host: no device length array to chase
         a.in_len = a.out_len = nullptr;
         a.in_const = a.out_const = dec_host_len;
@@ -570,7 +610,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
 
 static int glow_infer_impl(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
                            float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
-                           const uint64_t* row_seeds, const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
+                           const uint64_t* row_seeds, const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out,
+                           const int32_t* speaker_ids = nullptr) {
   if (!ctx || !out) return fail(MI355TTS_ERR_INVALID, "null argument");
   std::shared_ptr<GlowModel> gpin;
   CHECK(find_glow(ctx, glow, &gpin));
@@ -586,6 +627,7 @@ static int glow_infer_impl(mi355tts_ctx* ctx, int glow, const int64_t* ids, cons
   c.noise_ld = noise_ld;
   c.seed = seed;
   c.row_seeds = row_seeds;
+  c.speaker_ids = speaker_ids;
   c.audio = audio;
   c.flags = flags;
   int Pmax = 0;
@@ -601,6 +643,14 @@ extern "C" int mi355tts_glow_infer(mi355tts_ctx* ctx, int glow, const int64_t* i
                                    float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
                                    const mi355tts_audio_settings* audio, uint32_t flags, mi355tts_mel** out) {
   return glow_infer_impl(ctx, glow, ids, id_lens, B, ids_ld, noise_scale, length_scale, noise, noise_ld, seed, nullptr, audio, flags, out);
+}
+extern "C" int mi355tts_glow_infer_speakers(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                                            float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                                            const uint64_t* row_seeds, const int32_t* speaker_ids, const mi355tts_audio_settings* audio,
+                                            uint32_t flags, mi355tts_mel** out) {
+  if (!speaker_ids) return fail(MI355TTS_ERR_INVALID, "speaker_ids null");
+  return glow_infer_impl(ctx, glow, ids, id_lens, B, ids_ld, noise_scale, length_scale, noise, noise_ld, seed, row_seeds, audio, flags, out,
+                         speaker_ids);
 }
 extern "C" int mi355tts_glow_infer_rows(mi355tts_ctx* ctx, int glow, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
                                         float noise_scale, float length_scale, const uint64_t* row_seeds,

@@ -207,6 +207,8 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     out->epi = epi;
     out->cls = cls;
     out->bf16 = precision == MI355TTS_PRECISION_BF16 ? 1 : 3;
+    out->n_max = n_max;
+    out->pinned = false;
     out->grid = dim3((n_max + cols_t - 1) / cols_t, (c.mtiles16 * 32) / rows_t, B);
     out->flop = 2.0 * (double)c.Cout * c.Cin * (epi == EPI_UPSAMPLE ? c.K * a.up : c.K) * (double)n_max * B;
     out->empty = false;
@@ -409,7 +411,9 @@ static int group_ncu(const mi355tts_ctx* ctx) {
 // 128-row tile when together they give every CU more than one workgroup: as ONE grouped launch of the continuous-stream tile
 // with the dispatch laid out as a snake (run_group, group_snake_order) that step runs at 121 us where the 64 x 32 k-split tile
 // needs 133 (one stream; 108 against 124 with two streams in flight — profiles/r04_rb_diag_snake_order.txt).  Decided on the
-// plans, before the schedule is: the forked / one-by-one schedules then run the same tile arithmetic (same bits).
+// plans, before the schedule is: the forked / one-by-one schedules then run the same tile arithmetic (same bits).  (f32 only: the
+// same move in the split-bf16 mode — 128 x 64 tiles instead of the 8-wave k-split tile — measured 56.8 us against 54.4 us,
+// profiles/r04_ab17.txt.)
 static void promote_group_plans(mi355tts_ctx* ctx, Worker* w, ConvPlan* const* plans, int n) {
   // (option "rb_conv" = 0 / MI355TTS_NO_RB_CONV then run the chunked 128-row kernel in the plain order: same bits, slower)
   static const bool no_promote = [] { const char* e = std::getenv("MI355TTS_NO_GROUP_PROMOTE"); return e && std::atoi(e) != 0; }();
@@ -740,6 +744,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   g.len = a.in_len; g.len_mul = a.in_mul; g.len_const = a.in_const;
   g.w = c.g16_w; g.bias = c.g16_b; g.Cin = c.Cin; g.half = a.half; g.dil = a.dil; g.pad = a.pad;
   g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld;
+  g.cond = a.cond; g.cond_bs = a.cond_bs;
   ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B, s);
   const dim3 grid(gx, gy, B);
 #define GATE16_LAUNCH(KK, JJ) hipLaunchKernelGGL(HIP_KERNEL_NAME(gate16_kernel<KK, JJ>), grid, dim3(512), 0, s, g)

@@ -233,6 +233,10 @@ struct GlowModel {
   size_t dpp_w = 0, dpp_b = 0;  // proj's plain weight row [Fd] and bias, for the LayerNorm kernel's fused projection
   size_t dg1, db1, dg2, db2;
   std::vector<GlowBlock> blocks;
+  // multi-speaker voices (hp.n_speakers > 1): emb_g [n_speakers][gin]; the speaker half of proj_w.conv_1's weight
+  // [Fd][gin][k]; the flow blocks' cond_layer weights [n_blocks][2H n_layers][gin] and biases [n_blocks][2H n_layers]
+  size_t emb_g = 0, dp_wg = 0, cond_w = 0, cond_b = 0;
+  int gin() const { return hp.n_speakers > 1 ? hp.gin_channels : 0; }
 };
 struct HifiResConv {
   DevConv c1, c2;
@@ -277,7 +281,9 @@ static std::vector<std::pair<std::string, int64_t>> glow_manifest(const mi355tts
   auto add = [&](const std::string& n, int64_t e) { m.emplace_back(n, e); };
   const int64_t H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int64_t k = h.kernel_size, dk = H / std::max(1, h.n_heads), nrel = 2 * h.window_size + 1;
+  const int64_t gin = h.n_speakers > 1 ? h.gin_channels : 0;
   add("encoder.emb.weight", (int64_t)h.num_symbols * H);
+  if (gin) add("emb_g.weight", (int64_t)h.n_speakers * gin);
   if (h.prenet) {
     for (int i = 0; i < h.prenet_layers; ++i) {
       std::string p = "encoder.pre.conv_layers." + std::to_string(i);
@@ -310,7 +316,7 @@ static std::vector<std::pair<std::string, int64_t>> glow_manifest(const mi355tts
   }
   add("encoder.proj_m.weight", M * H);
   add("encoder.proj_m.bias", M);
-  add("encoder.proj_w.conv_1.weight", Fd * H * k);
+  add("encoder.proj_w.conv_1.weight", Fd * (H + gin) * k);  // input = [encoder output ; speaker vector] (models.py:114-116)
   add("encoder.proj_w.conv_1.bias", Fd);
   add("encoder.proj_w.norm_1.gamma", Fd);
   add("encoder.proj_w.norm_1.beta", Fd);
@@ -330,6 +336,10 @@ static std::vector<std::pair<std::string, int64_t>> glow_manifest(const mi355tts
     add(ic + ".weight_inv", (int64_t)h.n_split * h.n_split);
     add(cp + ".start.weight", H * half);
     add(cp + ".start.bias", H);
+    if (gin) {
+      add(cp + ".wn.cond_layer.weight", 2 * H * h.n_block_layers * gin);
+      add(cp + ".wn.cond_layer.bias", 2 * H * h.n_block_layers);
+    }
     for (int j = 0; j < h.n_block_layers; ++j) {
       std::string il = cp + ".wn.in_layers." + std::to_string(j);
       add(il + ".weight", 2 * H * H * h.kernel_size_dec);

@@ -115,6 +115,13 @@ static int check_glow_hp(const mi355tts_glow_hparams* h) {
     return fail(MI355TTS_ERR_INVALID, "bad GlowTTS hparams");
   if (h->kernel_size != 1 && h->kernel_size != 3 && h->kernel_size != 5) return fail(MI355TTS_ERR_INVALID, "bad kernel_size");
   if (h->kernel_size_dec != 3 && h->kernel_size_dec != 5) return fail(MI355TTS_ERR_INVALID, "bad kernel_size_dec");
+  if (h->n_speakers > 1) {
+    if (h->gin_channels < 1 || h->gin_channels > SPEAKER_MAX_GIN)
+      return fail(MI355TTS_ERR_INVALID, "a multi-speaker voice needs gin_channels in [1, %d] (got %d)", SPEAKER_MAX_GIN, h->gin_channels);
+  } else if (h->n_speakers < 0 || h->gin_channels != 0) {
+    // (the reference builds cond layers from gin_channels alone, models.py:287-301, but without emb_g nothing can feed them)
+    return fail(MI355TTS_ERR_INVALID, "gin_channels = %d without n_speakers > 1 is not supported", h->gin_channels);
+  }
   return 0;
 }
 static int check_hifi_hp(const mi355tts_hifigan_hparams* h) {
@@ -206,6 +213,10 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(emb, std::string("encoder.emb.weight"), (int64_t)h.num_symbols * H);
     gm->emb = ab.add(emb, (size_t)h.num_symbols * H);
   }
+  if (gm->gin()) {
+    TAKE(eg, std::string("emb_g.weight"), (int64_t)h.n_speakers * gm->gin());
+    gm->emb_g = ab.add(eg, (size_t)h.n_speakers * gm->gin());
+  }
   if (h.prenet) {
     for (int i = 0; i < h.prenet_layers; ++i) {
       std::string p = "encoder.pre.conv_layers." + std::to_string(i);
@@ -275,7 +286,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(b, std::string("encoder.proj_m.bias"), M);
     gm->proj_m = add_conv(ab, w, b, M, H, 1, ROWS_PLAIN);
     add_lin16(ab, gm->proj_m, w, b, M, H, 1);
-    TAKE(w1, std::string("encoder.proj_w.conv_1.weight"), (int64_t)Fd * H * k);
+    TAKE(w1, std::string("encoder.proj_w.conv_1.weight"), (int64_t)Fd * (H + gm->gin()) * k);
     TAKE(b1, std::string("encoder.proj_w.conv_1.bias"), Fd);
     TAKE(g1, std::string("encoder.proj_w.norm_1.gamma"), Fd);
     TAKE(e1, std::string("encoder.proj_w.norm_1.beta"), Fd);
@@ -285,6 +296,18 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(e2, std::string("encoder.proj_w.norm_2.beta"), Fd);
     TAKE(wp, std::string("encoder.proj_w.proj.weight"), Fd);
     TAKE(bp, std::string("encoder.proj_w.proj.bias"), 1);
+    const int gin = gm->gin();
+    std::vector<float> w1x;  // multi-speaker: conv_1's weight is [Fd][H + gin][k]; the encoder half goes to the conv kernels
+    if (gin) {
+      std::vector<float> wg((size_t)Fd * gin * k);
+      w1x.resize((size_t)Fd * H * k);
+      for (int co = 0; co < Fd; ++co) {
+        std::memcpy(&w1x[(size_t)co * H * k], w1 + (size_t)co * (H + gin) * k, sizeof(float) * (size_t)H * k);
+        std::memcpy(&wg[(size_t)co * gin * k], w1 + ((size_t)co * (H + gin) + H) * k, sizeof(float) * (size_t)gin * k);
+      }
+      gm->dp_wg = ab.add(wg);
+      w1 = w1x.data();
+    }
     gm->dp1 = add_conv(ab, w1, b1, Fd, H, k, ROWS_PLAIN);
     gm->dp2 = add_conv(ab, w2, b2, Fd, Fd, k, ROWS_PLAIN);
     add_lin16(ab, gm->dp1, w1, b1, Fd, H, k);
@@ -298,6 +321,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     gm->db2 = ab.add(e2, Fd);
   }
   const int C = M * h.n_sqz, half = C / 2;
+  std::vector<float> cond_w_all, cond_b_all;
   for (int b = 0; b < h.n_blocks_dec; ++b) {
     GlowBlock B;
     std::string an = "decoder.flows." + std::to_string(3 * b);
@@ -315,6 +339,13 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     TAKE(bs, cp + ".start.bias", H);
     B.start = add_conv(ab, ws, bs, H, half, 1, ROWS_PLAIN);
     B.t_st = add_col16(ab, ws, bs, H, half);
+    if (gm->gin()) {  // WN.cond_layer (layers.py:109-113): all blocks' weights side by side for speaker_cond_kernel
+      const int64_t n2 = (int64_t)2 * H * h.n_block_layers;
+      TAKE(wc, cp + ".wn.cond_layer.weight", n2 * gm->gin());
+      TAKE(bc, cp + ".wn.cond_layer.bias", n2);
+      cond_w_all.insert(cond_w_all.end(), wc, wc + n2 * gm->gin());
+      cond_b_all.insert(cond_b_all.end(), bc, bc + n2);
+    }
     for (int j = 0; j < h.n_block_layers; ++j) {
       std::string il = cp + ".wn.in_layers." + std::to_string(j);
       std::string rl = cp + ".wn.res_skip_layers." + std::to_string(j);
@@ -336,6 +367,10 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     gm->blocks.push_back(std::move(B));
   }
 #undef TAKE
+  if (gm->gin()) {
+    gm->cond_w = ab.add(cond_w_all);
+    gm->cond_b = ab.add(cond_b_all);
+  }
   CHECK(upload_arena(ctx, ab, &gm->arena));
   const float* A = gm->arena;
   for (auto& c : gm->pre_conv) fix(c, A);
@@ -769,11 +804,11 @@ extern "C" int mi355tts_mel_from_buffer(mi355tts_ctx* ctx, const float* mel, con
 // read-back and the final one (the two-call form adds a sync, a worker hand-over and a mel
 // object round trip through the caller).  Replaces the body of `_sentence_task`
 // (larynx/__init__.py:229-283) between the two log lines, pause padding included.
-extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
-                                   int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld,
-                                   uint64_t seed, const mi355tts_audio_settings* audio, float denoiser_strength,
-                                   int32_t pad_before, int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16,
-                                   int64_t wav_ld, uint32_t flags) {
+static int synthesize_impl(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B, int ids_ld,
+                           float noise_scale, float length_scale, const float* noise, int noise_ld, uint64_t seed,
+                           const int32_t* speaker_ids, const mi355tts_audio_settings* audio, float denoiser_strength,
+                           int32_t pad_before, int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16,
+                           int64_t wav_ld, uint32_t flags) {
   if (!ctx || !frames_out) return fail(MI355TTS_ERR_INVALID, "null argument");
   std::shared_ptr<GlowModel> gpin;
   std::shared_ptr<HifiModel> vpin;
@@ -791,6 +826,7 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
   g.noise = noise;
   g.noise_ld = noise_ld;
   g.seed = seed;
+  g.speaker_ids = speaker_ids;
   g.audio = audio;
   g.flags = flags & MI355TTS_IN_DEVICE;
   VocCall v;
@@ -809,7 +845,7 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
   CHECK(acquire_worker(ctx, &w));
   WorkerGuard guard{ctx, w};
   static const bool no_coalesce = [] { const char* e = std::getenv("MI355TTS_NO_GLOW_COALESCE"); return e && std::atoi(e) != 0; }();
-  if (B == 1 && !noise && !no_coalesce && ctx->glow_coalesce.load() && id_lens[0] <= ATTM_MAXP) {
+  if (B == 1 && !noise && !speaker_ids && !no_coalesce && ctx->glow_coalesce.load() && id_lens[0] <= ATTM_MAXP) {
     // a batch-1 call: its GlowTTS pass is shared with whichever other batch-1 calls are waiting right now (host_join.h)
     GlowJoinReq req;
     req.gm = gm;
@@ -869,6 +905,24 @@ extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, con
   for (int b = 0; b < B; ++b) frames_out[b] = mel->frames[b];
   CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), B, mel->M, mel->max_frames, v));
   return hifigan_run(ctx, w, hm, mel, v);
+}
+extern "C" int mi355tts_synthesize(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
+                                   int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld,
+                                   uint64_t seed, const mi355tts_audio_settings* audio, float denoiser_strength,
+                                   int32_t pad_before, int32_t pad_after, int32_t* frames_out, float* wav_f32, int16_t* wav_i16,
+                                   int64_t wav_ld, uint32_t flags) {
+  return synthesize_impl(ctx, glow, vocoder, ids, id_lens, B, ids_ld, noise_scale, length_scale, noise, noise_ld, seed, nullptr, audio,
+                         denoiser_strength, pad_before, pad_after, frames_out, wav_f32, wav_i16, wav_ld, flags);
+}
+// the same for a multi-speaker voice (larynx/glow_tts.py:116-130: the `speaker_id` setting)
+extern "C" int mi355tts_synthesize_speakers(mi355tts_ctx* ctx, int glow, int vocoder, const int64_t* ids, const int32_t* id_lens, int B,
+                                            int ids_ld, float noise_scale, float length_scale, const float* noise, int noise_ld,
+                                            uint64_t seed, const int32_t* speaker_ids, const mi355tts_audio_settings* audio,
+                                            float denoiser_strength, int32_t pad_before, int32_t pad_after, int32_t* frames_out,
+                                            float* wav_f32, int16_t* wav_i16, int64_t wav_ld, uint32_t flags) {
+  if (!speaker_ids) return fail(MI355TTS_ERR_INVALID, "speaker_ids null");
+  return synthesize_impl(ctx, glow, vocoder, ids, id_lens, B, ids_ld, noise_scale, length_scale, noise, noise_ld, seed, speaker_ids, audio,
+                         denoiser_strength, pad_before, pad_after, frames_out, wav_f32, wav_i16, wav_ld, flags);
 }
 
 // Pre-create `workers` workers (streams, pinned staging, side streams) and size their

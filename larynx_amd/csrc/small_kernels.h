@@ -891,4 +891,78 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
   if (i < n) p[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-speaker voices (glow_tts/models.py:304-306, 318-319).  g = F.normalize(emb_g(speaker)) is a [gin] vector per batch
+// row; everything the reference computes from it is a matrix-vector product, done here once per call:
+//   * workgroups x < nblk: cond[b][blk][:] = cond_layer_blk(g) (layers.py:109-113, 141-142 — a 1x1 conv of a length-1 tensor),
+//     the [2H * n_layers] gate offsets of flow block blk; a layer's gate conv adds its [2H] slice (conv_mfma.h EPI_GATE,
+//     gate16.h);
+//   * workgroup x = nblk: dps[b][co][k] = sum_ci W1[co][H + ci][k] g[ci], the speaker half of the duration predictor's first
+//     conv (models.py:114-116, 128-132: g is repeated along time and concatenated to the encoder output) per tap —
+//     speaker_dp_plane_kernel turns it into the [Fd][P] plane the conv of the encoder half takes as its residual.
+constexpr int SPEAKER_MAX_GIN = 1024;
+__global__ __launch_bounds__(256) void speaker_cond_kernel(const float* __restrict__ emb, int n_spk, int gin, const int* __restrict__ spk,
+                                                           const float* __restrict__ cw, const float* __restrict__ cb, int nblk, int n2,
+                                                           float* __restrict__ cond, const float* __restrict__ dpw, int FdK, int K,
+                                                           float* __restrict__ dps) {
+  GLOW_PRIO();
+  __shared__ float g[SPEAKER_MAX_GIN];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  int sid = spk[b];
+  sid = sid < 0 ? 0 : (sid >= n_spk ? n_spk - 1 : sid);  // (host ids are range-checked before the call)
+  const float* e = emb + (size_t)sid * gin;
+  float ss = 0.f;
+  for (int i = tid; i < gin; i += 256) {
+    const float v = e[i];
+    g[i] = v;
+    ss += v * v;
+  }
+  red[tid] = ss;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const float nrm = sqrtf(red[0]);
+  const float inv = 1.0f / (nrm > 1e-12f ? nrm : 1e-12f);  // F.normalize: x / max(||x||_2, eps)
+  for (int i = tid; i < gin; i += 256) g[i] *= inv;
+  __syncthreads();
+  if ((int)blockIdx.x < nblk) {
+    const int blk = blockIdx.x;
+    for (int o = tid; o < n2; o += 256) {
+      const float* w = cw + ((size_t)blk * n2 + o) * gin;
+      float acc = 0.f;
+      for (int i = 0; i < gin; ++i) acc += w[i] * g[i];
+      cond[((size_t)b * nblk + blk) * n2 + o] = acc + cb[(size_t)blk * n2 + o];
+    }
+  } else {
+    for (int o = tid; o < FdK; o += 256) {
+      const int co = o / K, kk = o - co * K;
+      const float* w = dpw + (size_t)co * gin * K + kk;
+      float acc = 0.f;
+      for (int i = 0; i < gin; ++i) acc += w[(size_t)i * K] * g[i];
+      dps[(size_t)b * FdK + o] = acc;
+    }
+  }
+}
+// gc[b][co][t] = sum over the taps k whose input position t + k - pad lies inside the row (the reference masks the
+// concatenated input before the conv, models.py:42: zero padding AND zeros past the row's length)
+__global__ __launch_bounds__(256) void speaker_dp_plane_kernel(const float* __restrict__ dps, int Fd, int K, int pad, const int* __restrict__ len,
+                                                               float* __restrict__ gc, long long bs, int ld) {
+  GLOW_PRIO();
+  const int b = blockIdx.z, co = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ld) return;
+  const int L = len[b];
+  float v = 0.f;
+  if (t < L) {
+    const float* s = dps + ((size_t)b * Fd + co) * K;
+    for (int k = 0; k < K; ++k) {
+      const int tt = t + k - pad;
+      if (tt >= 0 && tt < L) v += s[k];
+    }
+  }
+  gc[(long long)b * bs + (long long)co * ld + t] = v;
+}
+
 }  // namespace mi355tts

@@ -152,8 +152,11 @@ class Engine:
         seed: int = 0,
         audio_settings=None,
         row_seeds: typing.Optional[typing.Sequence[int]] = None,
+        speaker_ids: typing.Union[None, int, typing.Sequence[int]] = None,
     ) -> MelBatch:
         """`ids`: one int64 vector [P] or a list of them (variable length batch).
+        `speaker_ids`: a multi-speaker voice's speaker per row (one int = every row; the reference's `speaker_id`
+        setting, larynx/glow_tts.py:116-130) — required there, an error for a single-speaker voice.
         `noise`: optional [B, M, >=F] (or [M, >=F] for B=1) standing in for the
         reference's `torch.randn_like` draw.  Without it the device generator draws: row b from
         the stream `row_seeds[b]` (default `seed + b`: successive BATCHED calls must advance `seed` by the batch size)
@@ -177,9 +180,22 @@ class Engine:
             nz_ptr, nz_ld = noise.ctypes.data, noise.shape[2]
         a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
         out = C.c_void_p()
+        if row_seeds is not None and (noise is not None or len(row_seeds) != B):
+            raise ValueError("row_seeds: one seed per row, and no explicit noise")
+        if speaker_ids is not None:
+            spk = self._speaker_array(speaker_ids, B)
+            rs = None if row_seeds is None else np.array([int(x) & (2 ** 64 - 1) for x in row_seeds], np.uint64)
+            ffi.check(
+                self.lib,
+                self.lib.mi355tts_glow_infer_speakers(
+                    self._ctx, model, packed.ctypes.data, lens.ctypes.data_as(C.POINTER(C.c_int32)), B, packed.shape[1],
+                    float(noise_scale), float(length_scale), nz_ptr, nz_ld, int(seed) & (2 ** 64 - 1),
+                    rs.ctypes.data_as(C.POINTER(C.c_uint64)) if rs is not None else None,
+                    spk.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(a) if a is not None else None, 0, C.byref(out),
+                ),
+            )
+            return MelBatch(self, out.value)
         if row_seeds is not None:
-            if noise is not None or len(row_seeds) != B:
-                raise ValueError("row_seeds: one seed per row, and no explicit noise")
             rs = np.array([int(x) & (2 ** 64 - 1) for x in row_seeds], np.uint64)
             ffi.check(
                 self.lib,
@@ -199,6 +215,13 @@ class Engine:
             ),
         )
         return MelBatch(self, out.value)
+
+    @staticmethod
+    def _speaker_array(speaker_ids, B: int) -> np.ndarray:
+        spk = np.full(B, int(speaker_ids), np.int32) if np.isscalar(speaker_ids) else np.asarray(list(speaker_ids), np.int32)
+        if spk.shape != (B,):
+            raise ValueError("speaker_ids: one speaker per row")
+        return np.ascontiguousarray(spk)
 
     def glow_infer_raw(self, model, ids_ptr, lens, ids_ld, noise_scale, length_scale, noise_ptr=None, noise_ld=0,
                        seed=0, audio_settings=None, flags=0) -> MelBatch:
@@ -242,7 +265,7 @@ class Engine:
     def synthesize(self, glow: int, vocoder: int, ids, noise_scale: float = 0.667, length_scale: float = 1.0,
                    noise: typing.Optional[np.ndarray] = None, seed: int = 0, audio_settings=None,
                    denoiser_strength: float = 0.0, pad_before: int = 0, pad_after: int = 0, want_float: bool = False,
-                   frames_per_id_guess: float = 8.0):
+                   frames_per_id_guess: float = 8.0, speaker_ids: typing.Union[None, int, typing.Sequence[int]] = None):
         """ids -> (frames [B], wav_f32 [B, n] or None, wav_i16 [B, n]) through ONE fused call
         (`mi355tts_synthesize`): row b holds pad_before zeros, frames[b]*hop samples, then zeros.
         The frame count is data dependent; the output buffer is sized from a guess and the call
@@ -266,14 +289,18 @@ class Engine:
         lens_c = lens.ctypes.data_as(C.POINTER(C.c_int32))
         a = ffi.audio_settings_c(audio_settings) if audio_settings is not None else None
         frames = np.zeros(B, np.int32)
+        spk = self._speaker_array(speaker_ids, B) if speaker_ids is not None else None
         for attempt in range(2):
             f32 = np.empty((B, cap), np.float32) if want_float else None
             i16 = np.empty((B, cap), np.int16)
-            rc = self.lib.mi355tts_synthesize(
-                self._ctx, glow, vocoder, packed.ctypes.data, lens_c, B, ld, float(noise_scale), float(length_scale), nz_ptr,
-                nz_ld, int(seed) & (2 ** 64 - 1), C.byref(a) if a is not None else None, float(denoiser_strength),
-                int(pad_before), int(pad_after), frames.ctypes.data_as(C.POINTER(C.c_int32)), ffi.ptr(f32), i16.ctypes.data, cap, 0,
-            )
+            head = (self._ctx, glow, vocoder, packed.ctypes.data, lens_c, B, ld, float(noise_scale), float(length_scale), nz_ptr,
+                    nz_ld, int(seed) & (2 ** 64 - 1))
+            tail = (C.byref(a) if a is not None else None, float(denoiser_strength), int(pad_before), int(pad_after),
+                    frames.ctypes.data_as(C.POINTER(C.c_int32)), ffi.ptr(f32), i16.ctypes.data, cap, 0)
+            if spk is not None:
+                rc = self.lib.mi355tts_synthesize_speakers(*head, spk.ctypes.data_as(C.POINTER(C.c_int32)), *tail)
+            else:
+                rc = self.lib.mi355tts_synthesize(*head, *tail)
             n = int(frames.max()) * hop + pads
             if rc == -4 and attempt == 0 and n > cap:  # MI355TTS_ERR_TOO_SMALL: frames_out holds the real counts
                 cap = n

@@ -22,6 +22,7 @@ DEFAULT_LIBRARY = PACKAGE_DIR / "libmi355tts.so"
 MAX_STAGES = 8
 IN_DEVICE = 1
 OUT_DEVICE = 2
+ABI_VERSION = 2  # MI355TTS_ABI_VERSION of include/mi355tts.h
 PRECISION_F32 = 0
 PRECISION_BF16X3 = 1
 PRECISION_BF16 = 2
@@ -35,7 +36,7 @@ class GlowHParamsC(C.Structure):
             "kernel_size", "n_blocks_dec", "n_layers_enc", "n_heads",
             "dilation_rate", "kernel_size_dec", "n_block_layers", "n_sqz",
             "prenet", "window_size", "n_split", "mel_channels",
-            "prenet_kernel_size", "prenet_layers",
+            "prenet_kernel_size", "prenet_layers", "n_speakers", "gin_channels",
         )
     ]
 
@@ -99,6 +100,11 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
         [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,
          C.POINTER(AudioSettingsC), C.c_uint32, C.POINTER(_VP)],
     ),
+    "mi355tts_glow_infer_speakers": (
+        C.c_int,
+        [_VP, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,
+         C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(AudioSettingsC), C.c_uint32, C.POINTER(_VP)],
+    ),
     "mi355tts_mel_batch": (C.c_int, [_VP]),
     "mi355tts_mel_channels": (C.c_int, [_VP]),
     "mi355tts_mel_max_frames": (C.c_int, [_VP]),
@@ -116,6 +122,12 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
         C.c_int,
         [_VP, C.c_int, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,
          C.POINTER(AudioSettingsC), C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _VP, _VP, C.c_int64, C.c_uint32],
+    ),
+    "mi355tts_synthesize_speakers": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float, _VP, C.c_int, C.c_uint64,
+         C.POINTER(C.c_int32), C.POINTER(AudioSettingsC), C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _VP, _VP,
+         C.c_int64, C.c_uint32],
     ),
     "mi355tts_reserve": (C.c_int, [_VP] + [C.c_int] * 8),
     "mi355tts_op_gauss_noise": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_int, C.c_int, _VP]),
@@ -161,8 +173,8 @@ def load_library(path: typing.Union[str, os.PathLike, None] = None) -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         ver = lib.mi355tts_abi_version()
-        if ver != 1:
-            raise RuntimeError(f"{p}: ABI version {ver}, expected 1")
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"{p}: ABI version {ver}, expected {ABI_VERSION}")
         _libs[key] = lib
         return lib
 

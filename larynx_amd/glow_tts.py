@@ -23,7 +23,7 @@ _LOGGER = logging.getLogger("glow_tts")
 
 class HipGlowTextToSpeech(TextToSpeechModel):
     """Same constructor record, same `phonemes_to_mels(phoneme_ids, settings)` and
-    the same settings keys (`noise_scale`, `length_scale`; `larynx/glow_tts.py:118-121`)
+    the same settings keys (`noise_scale`, `length_scale`, `speaker_id`; `larynx/glow_tts.py:118-121`)
     as the reference class.  Differences a caller can see:
 
     * the returned object is a device-resident `MelBatch` (shape `[1, 80, F]`, like
@@ -90,19 +90,22 @@ class HipGlowTextToSpeech(TextToSpeechModel):
     def phonemes_to_mels(self, phoneme_ids: np.ndarray, settings: typing.Optional[SettingsType] = None) -> ARRAY_OR_TENSOR:
         noise_scale, length_scale = self.noise_scale, self.length_scale
         noise, seed = None, None
+        speaker_idx: typing.Optional[int] = None
         if settings:
             noise_scale = float(settings.get("noise_scale", noise_scale))
             length_scale = float(settings.get("length_scale", length_scale))
-            if settings.get("speaker_id") is not None:
-                raise ValueError("multi-speaker voices are not supported by the HIP backend")
+            speaker_idx = settings.get("speaker_id")  # larynx/glow_tts.py:121
             noise = settings.get("noise")
             seed = settings.get("seed")
         ids = np.asarray(phoneme_ids, dtype=np.int64).reshape(-1)
         if ids.size == 0:
             raise ValueError("empty phoneme id sequence")
         seed = next(self._seeds) if seed is None else int(seed)
+        # multi-speaker voices (larynx/glow_tts.py:125-130, 148: `g = speaker_id`): the library rejects a missing speaker for a
+        # multi-speaker voice and a speaker for a single-speaker one — both fail in the reference too
         return self.engine.glow_infer(
-            self.model_id, ids, noise_scale, length_scale, noise=noise, seed=seed, audio_settings=self._audio_settings
+            self.model_id, ids, noise_scale, length_scale, noise=noise, seed=seed, audio_settings=self._audio_settings,
+            speaker_ids=None if speaker_idx is None else int(speaker_idx),
         )
 
 

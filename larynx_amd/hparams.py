@@ -37,6 +37,11 @@ class GlowHParams:
     mel_channels: int = 80
     prenet_kernel_size: int = 5  # glow_tts/models.py:96 (hard-coded)
     prenet_layers: int = 3  # glow_tts/models.py:97 (hard-coded)
+    # multi-speaker voices (glow_tts/models.py:304-306, 318-319): n_speakers > 1 adds the speaker embedding `emb_g`
+    # [n_speakers, gin_channels]; its L2-normalised row conditions every WaveNet layer of the decoder (layers.py:109-113,
+    # 144-154) and is concatenated to the duration predictor's input (models.py:128-132)
+    n_speakers: int = 1
+    gin_channels: int = 0
 
     @staticmethod
     def from_config(cfg: typing.Mapping[str, typing.Any]) -> "GlowHParams":
@@ -48,9 +53,14 @@ class GlowHParams:
             m.get("hidden_channels_dec", hid) or hid
         ) != hid:
             raise ValueError("hidden_channels_enc/dec must equal hidden_channels")
+        n_spk = int(m.get("n_speakers", 1) or 0)
+        gin = int(m.get("gin_channels", 0) or 0)
+        if n_spk > 1 and gin <= 0:
+            raise ValueError("a multi-speaker voice needs gin_channels > 0")
+        if n_spk <= 1 and gin != 0:
+            # (the reference builds the conditioning layers from gin_channels alone but has no embedding to feed them)
+            raise ValueError(f"unsupported GlowTTS option gin_channels={gin} with n_speakers={n_spk}")
         unsupported = {
-            "n_speakers": (1, 0),
-            "gin_channels": (0,),
             "sigmoid_scale": (False,),
             "block_length": (None,),
         }
@@ -77,6 +87,8 @@ class GlowHParams:
             window_size=int(m.get("window_size", 4)),
             n_split=int(m.get("n_split", 4)),
             mel_channels=int(a.get("mel_channels", 80)),
+            n_speakers=n_spk if n_spk > 1 else 1,
+            gin_channels=gin if n_spk > 1 else 0,
         )
 
     def to_config(self) -> typing.Dict[str, typing.Any]:
@@ -87,8 +99,6 @@ class GlowHParams:
         d.update(
             hidden_channels_enc=self.hidden_channels,
             hidden_channels_dec=self.hidden_channels,
-            n_speakers=1,
-            gin_channels=0,
             sigmoid_scale=False,
             block_length=None,
             p_dropout=0.1,

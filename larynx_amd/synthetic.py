@@ -88,6 +88,7 @@ def make_glow_state_dict(
     sd["encoder.proj_m.weight"] = _normal(rng, (M, H, 1), 1.0 / math.sqrt(H))
     sd["encoder.proj_m.bias"] = _normal(rng, (M,), 0.1)
     w = "encoder.proj_w"
+    gin = hp.gin_channels if hp.n_speakers > 1 else 0
     sd[w + ".conv_1.weight"] = _normal(rng, (Fdp, H, k), 1.0 / math.sqrt(H * k))
     sd[w + ".conv_1.bias"] = _normal(rng, (Fdp,), 0.1)
     sd[w + ".norm_1.gamma"] = 1.0 + _normal(rng, (Fdp,), 0.1)
@@ -123,6 +124,19 @@ def make_glow_state_dict(
             rs = 2 * H if j < hp.n_block_layers - 1 else H
             sd[f"{cp}.wn.res_skip_layers.{j}.bias"] = _normal(rng, (rs,), 0.1)
             _weight_norm_pair(rng, (rs, H, 1), 1.0 / math.sqrt(H), f"{cp}.wn.res_skip_layers.{j}", sd)
+    if gin:
+        # Multi-speaker voice (models.py:304-306; layers.py:109-113; models.py:114-116).  Drawn from a generator of their
+        # own AFTER everything else, so the single-speaker tensors above are the same numbers with or without speakers.
+        # The speaker part is made strong enough to matter: a unit-norm g moves durations and gate pre-activations by a
+        # few tenths.
+        rg = np.random.Generator(np.random.PCG64(seed + 7919))
+        sd["emb_g.weight"] = rg.uniform(-0.1, 0.1, size=(hp.n_speakers, gin)).astype(np.float32)
+        wg = _normal(rg, (Fdp, gin, k), 1.5 / math.sqrt(gin * k))
+        sd[w + ".conv_1.weight"] = np.concatenate([sd[w + ".conv_1.weight"], wg], axis=1)
+        for b in range(hp.n_blocks_dec):
+            cp = f"decoder.flows.{3 * b + 2}"
+            sd[cp + ".wn.cond_layer.bias"] = _normal(rg, (2 * H * hp.n_block_layers,), 0.05)
+            _weight_norm_pair(rg, (2 * H * hp.n_block_layers, gin, 1), 0.5 / math.sqrt(gin), cp + ".wn.cond_layer", sd)
     # flows[0] (ActNorm) is applied LAST in the reverse pass (models.py:195-206):
     # use it to put the mel where a real voice's lives.
     sd["decoder.flows.0.logs"] = np.full((1, C, 1), -math.log(mel_std), np.float32) + _normal(rng, (1, C, 1), 0.05)

@@ -82,8 +82,22 @@ def attention(sd, prefix: str, x: np.ndarray, hp) -> np.ndarray:
     return nn.conv1d(out, _w(sd, prefix + ".conv_o"), _b(sd, prefix + ".conv_o"))
 
 
-def text_encoder(sd, ids: np.ndarray, hp, taps=None):
-    """`TextEncoder.forward` (models.py:118-140): returns x_m [M,P], logw [P]."""
+def speaker_vector(sd, hp, speaker_id) -> typing.Optional[np.ndarray]:
+    """`g = F.normalize(self.emb_g(g))` (models.py:318-319): the speaker's embedding row over max(its L2 norm, 1e-12);
+    None for a single-speaker voice."""
+    if getattr(hp, "n_speakers", 1) <= 1:
+        if speaker_id is not None:
+            raise ValueError("speaker_id given to a single-speaker voice (the reference has no emb_g there)")
+        return None
+    if speaker_id is None:
+        raise ValueError("a multi-speaker voice needs a speaker_id")
+    e = np.asarray(sd["emb_g.weight"], F32)[int(speaker_id)]
+    return (e / max(float(np.sqrt(np.sum(e.astype(np.float64) ** 2))), 1e-12)).astype(F32)
+
+
+def text_encoder(sd, ids: np.ndarray, hp, taps=None, g: typing.Optional[np.ndarray] = None):
+    """`TextEncoder.forward` (models.py:118-140): returns x_m [M,P], logw [P].  `g` [gin]: the speaker vector, repeated
+    along time and concatenated to the duration predictor's input (models.py:128-132)."""
     H = hp.hidden_channels
     k = hp.kernel_size
     x = (np.asarray(sd["encoder.emb.weight"], F32)[ids] * F32(math.sqrt(H))).T.copy()  # [H,P]
@@ -113,7 +127,8 @@ def text_encoder(sd, ids: np.ndarray, hp, taps=None):
     x_m = nn.conv1d(x, _w(sd, "encoder.proj_m"), _b(sd, "encoder.proj_m"))
     # DurationPredictor: conv -> ReLU -> LayerNorm (models.py:39-49)
     w = "encoder.proj_w"
-    d = nn.conv1d(x, _w(sd, w + ".conv_1"), _b(sd, w + ".conv_1"), padding=k // 2)
+    x_dp = x if g is None else np.concatenate([x, np.repeat(g[:, None], x.shape[1], axis=1)], axis=0).astype(F32)
+    d = nn.conv1d(x_dp, _w(sd, w + ".conv_1"), _b(sd, w + ".conv_1"), padding=k // 2)
     d = _ln(sd, w + ".norm_1", np.maximum(d, 0))
     d = nn.conv1d(d, _w(sd, w + ".conv_2"), _b(sd, w + ".conv_2"), padding=k // 2)
     d = _ln(sd, w + ".norm_2", np.maximum(d, 0))
@@ -150,15 +165,21 @@ def unsqueeze(x: np.ndarray, n: int) -> np.ndarray:
     return x.reshape(n, C // n, T).transpose(1, 2, 0).reshape(C // n, T * n).copy()
 
 
-def wavenet(sd, prefix: str, x: np.ndarray, hp) -> np.ndarray:
-    """`WN.forward` (layers.py:138-162), g=None."""
+def wavenet(sd, prefix: str, x: np.ndarray, hp, g: typing.Optional[np.ndarray] = None) -> np.ndarray:
+    """`WN.forward` (layers.py:138-162).  `g` [gin]: `cond_layer(g)` (a 1x1 conv of a length-1 tensor = a matrix-vector
+    product) gives every layer a [2H] offset added to its gate pre-activation (layers.py:141-154)."""
     H = hp.hidden_channels
     kd = hp.kernel_size_dec
     out = np.zeros_like(x)
+    cond = None
+    if g is not None:
+        cond = (_w(sd, f"{prefix}.cond_layer")[:, :, 0] @ g + _b(sd, f"{prefix}.cond_layer")).astype(F32)
     for i in range(hp.n_block_layers):
         d = hp.dilation_rate ** i
         pad = (kd * d - d) // 2
         x_in = nn.conv1d(x, _w(sd, f"{prefix}.in_layers.{i}"), _b(sd, f"{prefix}.in_layers.{i}"), dilation=d, padding=pad)
+        if cond is not None:
+            x_in = (x_in + cond[i * 2 * H : (i + 1) * 2 * H, None]).astype(F32)
         acts = np.tanh(x_in[:H]) * nn.sigmoid(x_in[H:])  # utils.py:31-38
         rs = nn.conv1d(acts, _w(sd, f"{prefix}.res_skip_layers.{i}"), _b(sd, f"{prefix}.res_skip_layers.{i}"))
         if i < hp.n_block_layers - 1:
@@ -169,7 +190,7 @@ def wavenet(sd, prefix: str, x: np.ndarray, hp) -> np.ndarray:
     return out
 
 
-def flow_decoder_reverse(sd, z: np.ndarray, hp, taps=None) -> np.ndarray:
+def flow_decoder_reverse(sd, z: np.ndarray, hp, taps=None, g: typing.Optional[np.ndarray] = None) -> np.ndarray:
     """`FlowSpecDecoder.forward(reverse=True)` (models.py:191-209): squeeze,
     then for blocks 11..0: CouplingBlock -> InvConvNear -> ActNorm, all reversed."""
     x = squeeze(z, hp.n_sqz)
@@ -181,7 +202,7 @@ def flow_decoder_reverse(sd, z: np.ndarray, hp, taps=None) -> np.ndarray:
         # CouplingBlock reverse (attentions.py:119-142)
         x0, x1 = x[:half], x[half:]
         h = nn.conv1d(x0, _w(sd, cp + ".start"), _b(sd, cp + ".start"))
-        h = wavenet(sd, cp + ".wn", h, hp)
+        h = wavenet(sd, cp + ".wn", h, hp, g)
         o = nn.conv1d(h, _w(sd, cp + ".end"), _b(sd, cp + ".end"))
         m, logs = o[:half], o[half:]
         x = np.concatenate([x0, (x1 - m) * np.exp(-logs)], axis=0).astype(F32)
@@ -208,12 +229,14 @@ def glow_tts_infer(
     noise_scale: float = 0.667,
     length_scale: float = 1.0,
     taps: typing.Optional[dict] = None,
+    speaker_id: typing.Optional[int] = None,
 ) -> np.ndarray:
     """ids int64 [P] -> mel float32 [M, F].  `noise` is the N(0,1) tensor the
     reference draws with `torch.randn_like(z_m)` (models.py:348), laid out
     [M, >=F]; None means zeros (equivalent to noise_scale=0)."""
     ids = np.asarray(ids, np.int64)
-    x_m, logw = text_encoder(sd, ids, hp, taps)
+    g = speaker_vector(sd, hp, speaker_id)  # models.py:318-319
+    x_m, logw = text_encoder(sd, ids, hp, taps, g)
     w_ceil, F, idx = durations_to_frames(logw, length_scale, hp.n_sqz)
     if taps is not None:
         taps["w_ceil"] = w_ceil
@@ -227,4 +250,4 @@ def glow_tts_infer(
     z = z.astype(F32)
     if taps is not None:
         taps["z"] = z.copy()
-    return flow_decoder_reverse(sd, z, hp, taps)
+    return flow_decoder_reverse(sd, z, hp, taps, g)

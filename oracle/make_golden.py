@@ -84,8 +84,8 @@ def build_ref_glow(gm, hp: HP.GlowHParams, sd):
         dilation_rate=hp.dilation_rate,
         n_block_layers=hp.n_block_layers,
         p_dropout_dec=0.05,
-        n_speakers=1,
-        gin_channels=0,
+        n_speakers=hp.n_speakers,
+        gin_channels=hp.gin_channels,
         n_split=hp.n_split,
         n_sqz=hp.n_sqz,
         sigmoid_scale=False,
@@ -122,7 +122,7 @@ def build_ref_hifigan(hm, hc, hp: HP.HifiGanHParams, sd):
     return gen
 
 
-def ref_sentence(gm_model, gen, ra, ids, noise, noise_scale, length_scale, audio_cfg):
+def ref_sentence(gm_model, gen, ra, ids, noise, noise_scale, length_scale, audio_cfg, speaker_id=None):
     """The reference's `_sentence_task` data path (larynx/__init__.py:229-257) on
     the torch backend (larynx/glow_tts.py:123-151, larynx/hifi_gan.py:134-169)."""
     import torch
@@ -138,7 +138,8 @@ def ref_sentence(gm_model, gen, ra, ids, noise, noise_scale, length_scale, audio
     torch.randn_like = fixed_randn_like
     try:
         with torch.no_grad():
-            (mel, *_), _, (attn, logw, _) = gm_model(text, lengths, noise_scale=noise_scale, length_scale=length_scale, g=None)
+            g = None if speaker_id is None else torch.LongTensor([int(speaker_id)])  # larynx/glow_tts.py:125-130
+            (mel, *_), _, (attn, logw, _) = gm_model(text, lengths, noise_scale=noise_scale, length_scale=length_scale, g=g)
     finally:
         torch.randn_like = orig
     mel = mel.cpu()
@@ -151,6 +152,8 @@ def ref_sentence(gm_model, gen, ra, ids, noise, noise_scale, length_scale, audio
     if settings.do_dynamic_range_compression:
         mels = settings.dynamic_range_compression(mels)
     mels = np.asarray(mels, np.float32)
+    if gen is None:  # acoustic model only (make_golden_speakers.py)
+        return mel.numpy()[0], mels[0], None, None, logw.numpy()[0, 0]
     with torch.no_grad():
         audio = gen(torch.from_numpy(mels)).squeeze(0).cpu().numpy()
     audio_i16 = ra.audio_float_to_int16(audio).squeeze()

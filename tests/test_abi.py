@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_symbol():
     for name in header_symbols():
         assert hasattr(lib, name), name
     lib.mi355tts_abi_version.restype = ctypes.c_int
-    assert lib.mi355tts_abi_version() == 1
+    assert lib.mi355tts_abi_version() == 2
 
 
 def test_manifest_matches_reference_checkpoint_keys():

@@ -564,4 +564,42 @@ PY
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
 }
 
+diag_row_stride() {
+# does the power-of-two factor of the activation row stride matter?  stage-1 geometry at 617 / 624 / 640 / 656 frames (strides of
+# 2^8 x 617, 2^12 x 39, 2^15 x 5, 2^12 x 41 bytes) in the harness, and the vocoder alone at those frame counts
+cd $GRAFT_REPO_ROOT
+S="-DCG_C=128 -DRB_NEW=1"
+bash tools/gpu/rb_diag.sh r04_diag19 "$S -DCG_L=39488" "$S -DCG_L=39936" "$S -DCG_L=40960" "$S -DCG_L=41984" > /dev/null
+grep -E "^##|L x8|1 stream|2 stream" gpurun_out/r04_diag19/rb_diag.log
+for f in 617 624 640 656; do echo "== frames $f"; PYTHONPATH=. timeout 300 python tools/ab_inproc.py --frames $f --rounds 4 larynx_amd/libmi355tts.so 2>&1 | grep wall; done
+}
+
+ab_bf16_snake() {
+# split-bf16 mode: the 256-channel stage on 128 x 64 tiles dealt as a snake (BF_E, promote_group_plans) against the 8-wave
+# k-split 128 x 128 tile (MI355TTS_NO_GROUP_PROMOTE=1): kernel stats, the half-mode bench line, parity.  NOT adopted
+# (profiles/r04_ab17.txt): the BF_E tile and its promotion were taken out again — this function records how it was measured
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_ab17; mkdir -p $O
+B="python bench.py --precision bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in old new; do
+  e=0; [ $v = old ] && e=1
+  MI355TTS_NO_GROUP_PROMOTE=$e timeout 300 rocprofv3 --kernel-trace --stats -d $O/t_$v -o t --output-format csv -- $B > $O/t_$v.log 2>&1
+  f=$(find $O/t_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; grep -E "bf16" $f | cut -c1-150
+  rm -rf $O/t_$v
+done
+B2="python bench.py --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-steady-state"
+for i in 1 2; do
+  MI355TTS_NO_GROUP_PROMOTE=1 timeout 300 $B2 > $O/old_$i.json 2> $O/old_$i.err
+  timeout 300 $B2 > $O/new_$i.json 2> $O/new_$i.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab17/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); h = j["half_mode"]
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "half: %.1f utt/s" % h["utterances_per_sec"], "lat %.3f ms" % h["latency_ms_single_stream"], "class %.3f ms" % h["resblock_class_ms_per_step"], "frac %.3f" % h["roofline"]["frac"])
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "bf16" 2>&1 | grep -E "passed|failed|Error" | tail -3
+}
+
 "$@"
