@@ -926,6 +926,32 @@ inline void group_snake_order(ConvGroupArgs& g, int ncu, int slots) {
   g.seg_off[nout] = o;
   g.nseg = nout;
 }
+
+// What that dispatch order does to the busiest CU: (largest per-CU sum of tile costs) / (mean per-CU sum), for `real[m]` real
+// tiles per member (the rest of a member's range is padding that exits at once) of cost `cost[m]` each, workgroup i on CU
+// i mod ncu.  1.0 = perfectly even.  promote_group_plans (host_launch.h) moves a step to the big tile only when this is small:
+// just above one workgroup per CU the big tile's few extra workgroups double the busiest CUs' work.
+inline double group_order_imbalance(const ConvGroupArgs& g, int ncu, const int real[3], const double cost[3]) {
+  if (ncu <= 0 || ncu > 4096) return 1e9;
+  double load[4096];
+  for (int c = 0; c < ncu; ++c) load[c] = 0.0;
+  double total = 0.0;
+  auto place = [&](int lin, int m, int l) {
+    if (l >= real[m]) return;
+    load[lin % ncu] += cost[m];
+    total += cost[m];
+  };
+  if (g.nseg) {
+    for (int sg = 0; sg < g.nseg; ++sg)
+      for (int lin = g.seg_off[sg]; lin < g.seg_off[sg + 1]; ++lin) place(lin, g.seg_m[sg], g.seg_first[sg] + (lin - g.seg_off[sg]));
+  } else {
+    for (int m = 0; m < 3; ++m)
+      for (int lin = g.off[m]; lin < g.off[m + 1]; ++lin) place(lin, m, lin - g.off[m]);
+  }
+  double mx = 0.0;
+  for (int c = 0; c < ncu; ++c) mx = load[c] > mx ? load[c] : mx;
+  return total > 0.0 ? mx / (total / ncu) : 1e9;
+}
 template <int K0, int K1, int K2, int CI_C, int MB, int NB, int WN, int KS, int H0, int H1, int H2, int WM = 1>
 // (second launch bound = waves per SIMD: 4 keeps every member under 128 VGPRs, i.e. two 8-wave workgroups per CU)
 __global__ __launch_bounds__(64 * WM * WN * KS, ((NB == 1 && MB == 2) || WM == 4 || (MB == 1 && NB == 2 && KS == 4)) ? 4 : 1) void conv_group_kernel(const ConvGroupArgs g) {

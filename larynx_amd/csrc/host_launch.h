@@ -420,15 +420,32 @@ static void promote_group_plans(mi355tts_ctx* ctx, Worker* w, ConvPlan* const* p
   (void)w;
   if (n != 3 || no_promote) return;
   int total = 0, taps = 0;
+  int tiles[3] = {0, 0, 0};  // by member in tap order 11, 7, 3
   for (int i = 0; i < 3; ++i) {
     const ConvPlan& p = *plans[i];
     if (p.empty || p.bf16 || p.pinned || p.epi != EPI_LINEAR || p.cls != KC_RESBLOCK || p.shape == TILE_M128 || p.grid.z != 1 ||
         p.n_max <= 0 || (p.a.x_ld % 4) || (p.K != 11 && p.K != 7 && p.K != 3) || !rb_member_ok(p.a, p.K))
       return;
     taps |= p.K == 11 ? 1 : p.K == 7 ? 2 : 4;
+    tiles[p.K == 11 ? 0 : p.K == 7 ? 1 : 2] = ((p.n_max + 63) / 64) * (p.a.rows / 128);
     total += (((p.n_max + 63) / 64) * (p.a.rows / 128) + 7) & ~7;
   }
-  if (taps != 7 || total <= group_ncu(ctx)) return;
+  const int ncu = group_ncu(ctx);
+  if (taps != 7 || total <= ncu) return;
+  if (total <= 4 * ncu) {
+    // All resident at once: nothing is dealt dynamically, so the launch lasts as long as its busiest CU.  The big tile runs at
+    // ~0.83 of peak against ~0.65-0.70 for the k-split tile it replaces (whose many small workgroups ARE dealt dynamically):
+    // it wins while the snake keeps the busiest CU within 1.25x of the mean (measured by utterance length, profiles/r04_ab18.txt; 1.09 at 624 frames of 'high': 121 us against 133; just above one
+    // workgroup per CU — shorter utterances, narrower stages — the few second-round tiles double the busiest CUs' work).
+    const char* env = std::getenv("MI355TTS_PROMOTE_MAX_IMBALANCE");  // (read per step, like MI355TTS_GROUP_NCU: tests move it)
+    const double max_imbalance = env ? std::atof(env) : 1.25;
+    ConvGroupArgs g;
+    g.off[0] = 0;
+    for (int m = 0; m < 3; ++m) g.off[m + 1] = g.off[m] + ((tiles[m] + 7) & ~7);
+    group_snake_order(g, ncu, 4 * ncu);
+    const double cost[3] = {11.0, 7.0, 3.0};
+    if (group_order_imbalance(g, ncu, tiles, cost) > max_imbalance) return;
+  }
   for (int i = 0; i < 3; ++i) {
     ConvPlan& p = *plans[i];
     p.shape = TILE_M128;

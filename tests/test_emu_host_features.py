@@ -395,7 +395,7 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
     """At batch 1 the same-geometry ResBlock convs of a step that plan_conv left on the small tiles move to the 128-row tile
     when together they give every CU more than one workgroup (`promote_group_plans`, decided on the plans: every schedule then
     runs the same tile arithmetic), and a grouped launch whose workgroups are all resident at once is dispatched as a snake
-    (`group_snake_order`: round 0 longest first, round 1 shortest first).  `MI355TTS_GROUP_NCU` = 24 makes the 300-frame shape
+    (`group_snake_order`: round 0 longest first, round 1 shortest first).  `MI355TTS_GROUP_NCU` = 24 makes the 490-frame shape
     such a launch (16 + 16 + 16 workgroups in rounds of 24: segments k11 x16, k7 x8, k3 x16, k7 x8).  The order is a
     permutation of the tiles: same bits as the chunked 128-row kernel in its plain order (option rb_conv = 0), as the forked
     schedule, and as the plain order of the same kernel."""
@@ -405,7 +405,7 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
     v = emu_engine.load_hifigan(hp, sd)
     rng = np.random.default_rng(14)
     try:
-        mel = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 300))).astype(np.float32)
+        mel = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 490))).astype(np.float32)  # 980 columns: 16 tiles per member
         mb = emu_engine.mel_from_numpy(mel)
         monkeypatch.setenv("MI355TTS_GROUP_NCU", "24")
         emu_engine.set_profiling(True)
@@ -435,6 +435,16 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
         # (MI355TTS_M128_MIN_TILES also moves the upsamplers to their 128-row tile — another summation order: round-off here)
         assert np.abs(plain - promoted).max() <= 1e-6
         assert not np.array_equal(small, promoted) and np.abs(small - promoted).max() <= 1e-6  # the k-split tile sums in another order
+        # the rule: a step just above one workgroup per CU stays on the small tiles — 6 tiles per member on "16 CUs" would put
+        # 11 + 3 tap-units on six CUs where the mean is 7.9 (group_order_imbalance 1.78 > 1.25)
+        mel2 = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 170))).astype(np.float32)
+        mb2 = emu_engine.mel_from_numpy(mel2)
+        small2, _ = emu_engine.hifigan_infer(v, mb2)           # MI355TTS_GROUP_NCU = 1024: nothing promoted
+        monkeypatch.setenv("MI355TTS_GROUP_NCU", "16")
+        kept, _ = emu_engine.hifigan_infer(v, mb2)
+        monkeypatch.setenv("MI355TTS_PROMOTE_MAX_IMBALANCE", "2")
+        forced, _ = emu_engine.hifigan_infer(v, mb2)
+        assert np.array_equal(kept, small2) and not np.array_equal(forced, small2) and np.abs(forced - small2).max() <= 1e-6
     finally:
         emu_engine.set_profiling(False)
         emu_engine.unload(v)

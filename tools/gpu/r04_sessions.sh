@@ -602,4 +602,28 @@ PY
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "bf16" 2>&1 | grep -E "passed|failed|Error" | tail -3
 }
 
+ab_promote_rule() {
+# when does the 128-row tile + snake beat the k-split tile on the 256-channel stage?  the vocoder alone at several utterance
+# lengths with the promotion forced (MI355TTS_PROMOTE_MAX_IMBALANCE=100), off (=0) and by the rule (busiest CU <= 1.2 x mean);
+# then config 3 (256 utterances of 60 ... 200 ids) with the rule and without promotion
+cd $GRAFT_REPO_ROOT
+for f in 360 440 520 560 600 680 700 760 840 1040 1100; do
+  for v in 100 0 1.2; do
+    echo -n "frames $f max_imbalance $v: "; MI355TTS_PROMOTE_MAX_IMBALANCE=$v PYTHONPATH=. timeout 300 python tools/ab_inproc.py --frames $f --rounds 3 --calls 10 larynx_amd/libmi355tts.so 2>&1 | grep wall | sed "s/libmi355tts.so *//"
+  done
+done
+O=gpurun_out/r04_ab18; mkdir -p $O
+B2="python bench.py --no-cpu-baseline --no-config4 --no-config5 --no-half-mode --no-steady-state"
+for i in 1 2; do
+  MI355TTS_NO_GROUP_PROMOTE=1 timeout 400 $B2 > $O/old_$i.json 2> $O/old_$i.err
+  timeout 400 $B2 > $O/new_$i.json 2> $O/new_$i.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04_ab18/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1][:-5], "value %.1f" % j["value"], "config3 %.1f utt/s" % j["config3"]["utterances_per_sec"])
+PY
+}
+
 "$@"
