@@ -279,6 +279,9 @@ int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
+/* Median elapsed time (microseconds) of `pairs` EMPTY event pairs on an idle stream: what the two hipEventRecord calls around a
+ * profiled launch add to its event-timed duration (rocprofv3's kernel durations do not contain it). */
+int mi355tts_profile_event_overhead(mi355tts_ctx* ctx, int pairs, double* us_out);
 
 #ifdef __cplusplus
 }

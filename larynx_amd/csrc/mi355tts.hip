@@ -1262,6 +1262,35 @@ extern "C" int mi355tts_profile_reset(mi355tts_ctx* ctx) {
   for (auto& a : ctx->prof) a = mi355tts_ctx::Acc();
   return 0;
 }
+// What the two event records of a ProfScope cost by themselves: `pairs` empty pairs (hipEventRecord a, hipEventRecord b,
+// nothing between) on an idle stream of this context's device, median elapsed in microseconds.  A profiled launch's event time
+// is its kernel's duration plus at least this (4.5 us on MI355X; rocprofv3's kernel durations do not contain it), so bench.py
+// reports its event-timed launch durations with and without it.
+extern "C" int mi355tts_profile_event_overhead(mi355tts_ctx* ctx, int pairs, double* us_out) {
+  if (!ctx || !us_out || pairs < 1 || pairs > 4096) return fail(MI355TTS_ERR_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t st = nullptr;
+  HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  std::vector<float> el;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  for (int i = 0; i < pairs + 3 && e == hipSuccess; ++i) {
+    hipEventRecord(a, st);
+    hipEventRecord(b, st);
+    e = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (i >= 3) el.push_back(ms);  // (the first records of a new stream are slower)
+  }
+  if (a) hipEventDestroy(a);
+  if (b) hipEventDestroy(b);
+  hipStreamDestroy(st);
+  if (e != hipSuccess) return fail(MI355TTS_ERR_HIP, "event overhead: %s", hipGetErrorString(e));
+  std::sort(el.begin(), el.end());
+  *us_out = 1000.0 * (double)el[el.size() / 2];
+  return 0;
+}
 extern "C" int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap) {
   if (!ctx || !buf || cap <= 2) return fail(MI355TTS_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -439,6 +439,12 @@ class Engine:
     def profile_reset(self):
         ffi.check(self.lib, self.lib.mi355tts_profile_reset(self._ctx))
 
+    def profile_event_overhead_us(self, pairs: int = 64) -> float:
+        """Median elapsed time of an EMPTY event pair on an idle stream (`mi355tts_profile_event_overhead`)."""
+        us = C.c_double(0.0)
+        ffi.check(self.lib, self.lib.mi355tts_profile_event_overhead(self._ctx, int(pairs), C.byref(us)))
+        return float(us.value)
+
     def profile(self) -> dict:
         buf = C.create_string_buffer(4096)
         ffi.check(self.lib, self.lib.mi355tts_profile_json(self._ctx, buf, 4096))
