@@ -265,7 +265,10 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * order); "rb_conv" (0/1, default 1) — the grouped 128-row ResBlock launches on the continuous-stream tile of rb_conv.h
  * (0 = the chunked tile of conv_mfma.h; same bits); "rb_pair" (0/1, default 1) — the fused ResBlock steps of the 64- / 32-channel
  * stages on the 4-wave tile without a k-split (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h: same results up to
- * summation order); "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
+ * summation order); "group_promote" (0/1, default 1) — at batch 1 the same-geometry ResBlock convs of a step that are too short
+ * for the 128-row tile's own threshold move to it when the dispatcher's round-robin deal of their (all resident) workgroups,
+ * laid out as a snake, stays balanced (0 = they keep the 64 x 32 k-split tile: same results up to summation order);
+ * "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
  * the call's worker; "glow_coalesce" (below).  The schedule options give the same bits under
  * every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);

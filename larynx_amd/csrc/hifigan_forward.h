@@ -186,6 +186,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   const bool opt_serial = ctx->serial_branches.load(), opt_group = ctx->mrf_group.load(), opt_small = ctx->mrf_small.load();
   w->o_rb_conv = ctx->rb_conv.load();
   w->o_rb_pair = ctx->rb_pair.load();
+  w->o_group_promote = ctx->group_promote.load();
   const bool split_out = hifi_split_out(opt_serial, h);
   // grouped (default): the chains stay on ONE stream and the same-geometry launches of a step go out as
   // one grouped launch (conv_group_kernel / pair_group_kernel) — the chip is filled from one launch, with

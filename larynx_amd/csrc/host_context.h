@@ -55,7 +55,7 @@ struct Worker {
   hipEvent_t ev_join[2] = {nullptr, nullptr};
   // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
   // a mi355tts_set_option from another thread never changes a call's schedule half way through)
-  bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true;
+  bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true, o_group_promote = true;
   // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
   // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
   hipStream_t gstream = nullptr;
@@ -87,6 +87,7 @@ struct mi355tts_ctx {
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
+  std::atomic<bool> group_promote{true};  // batch-1 ResBlock steps move to the 128-row tile when the snake deal is balanced (promote_group_plans)
   std::atomic<bool> rb_pair{true};    // fused ResBlock steps (64 / 32 channels) on the 4-wave tile without a k-split (rb_pair.h)
   // mi355tts_synthesize: GlowTTS on a high-priority stream of the call's worker (see Worker::gstream).  The hardware queues
   // run one kernel at a time each and the runtime maps all bulk streams onto 4 of them: a call's chain of ~140 small

@@ -417,8 +417,7 @@ static int group_ncu(const mi355tts_ctx* ctx) {
 static void promote_group_plans(mi355tts_ctx* ctx, Worker* w, ConvPlan* const* plans, int n) {
   // (option "rb_conv" = 0 / MI355TTS_NO_RB_CONV then run the chunked 128-row kernel in the plain order: same bits, slower)
   static const bool no_promote = [] { const char* e = std::getenv("MI355TTS_NO_GROUP_PROMOTE"); return e && std::atoi(e) != 0; }();
-  (void)w;
-  if (n != 3 || no_promote) return;
+  if (n != 3 || no_promote || !w->o_group_promote) return;
   int total = 0, taps = 0;
   int tiles[3] = {0, 0, 0};  // by member in tap order 11, 7, 3
   for (int i = 0; i < 3; ++i) {

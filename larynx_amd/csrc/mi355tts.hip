@@ -1235,6 +1235,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->rb_conv = value != 0;
     return 0;
   }
+  if (std::strcmp(name, "group_promote") == 0) {
+    ctx->group_promote = value != 0;
+    return 0;
+  }
   if (std::strcmp(name, "rb_pair") == 0) {
     ctx->rb_pair = value != 0;
     return 0;

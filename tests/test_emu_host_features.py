@@ -423,6 +423,11 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
             forked, _ = emu_engine.hifigan_infer(v, mb)   # promoted; one launch per conv
         finally:
             emu_engine.set_option("mrf_group", 1)
+        emu_engine.set_option("group_promote", 0)
+        try:
+            unpromoted, _ = emu_engine.hifigan_infer(v, mb)  # option off: the small tiles of the plan
+        finally:
+            emu_engine.set_option("group_promote", 1)
         monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
         monkeypatch.setenv("MI355TTS_GROUP_NCU", "8")     # 48 workgroups > 4 x 8: the plain order of the same kernel
         plain, _ = emu_engine.hifigan_infer(v, mb)
@@ -435,6 +440,7 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
         # (MI355TTS_M128_MIN_TILES also moves the upsamplers to their 128-row tile — another summation order: round-off here)
         assert np.abs(plain - promoted).max() <= 1e-6
         assert not np.array_equal(small, promoted) and np.abs(small - promoted).max() <= 1e-6  # the k-split tile sums in another order
+        assert np.array_equal(unpromoted, small)
         # the rule: a step just above one workgroup per CU stays on the small tiles — 6 tiles per member on "16 CUs" would put
         # 11 + 3 tap-units on six CUs where the mean is 7.9 (group_order_imbalance 1.78 > 1.25)
         mel2 = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 170))).astype(np.float32)

@@ -371,6 +371,34 @@ def test_vocoder_launch_counts_on_the_device(gpu_engine, quality, resblock, narr
     assert prof["conv_mfma.hifigan_upsample"]["launches"] == 4 and prof["conv_mfma.hifigan_pre_post"]["launches"] == 2, prof
 
 
+def test_promoted_stage_really_runs_on_the_device(gpu_engine):
+    """The 256-channel stage of 'high' at batch 1 takes the 128-row tile in snake order (`promote_group_plans`; the golden parity
+    tests above run through it).  Option "group_promote" = 0 sends the same step to the 64 x 32 k-split tile — another summation
+    order — so: the two settings give different bits (the promotion is live on this device, not a silent fallback), both within
+    the waveform bar of the reference's output, and the launch count of the class is the same 18."""
+    c = load_case("ljspeech_high_S120")
+    (gsd, g), (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"][None])
+    gpu_engine.set_profiling(True)
+    gpu_engine.profile_reset()
+    on, _ = gpu_engine.hifigan_infer(v, mb)
+    n_on = gpu_engine.profile()["conv_mfma.hifigan_resblock"]["launches"]
+    gpu_engine.set_option("group_promote", 0)
+    try:
+        gpu_engine.profile_reset()
+        off, _ = gpu_engine.hifigan_infer(v, mb)
+        n_off = gpu_engine.profile()["conv_mfma.hifigan_resblock"]["launches"]
+    finally:
+        gpu_engine.set_option("group_promote", 1)
+        gpu_engine.set_profiling(False)
+    n = c["wav"].shape[0]
+    assert n_on == n_off == 18
+    assert not np.array_equal(on, off)
+    for wav in (on, off):
+        assert np.sqrt(np.mean((wav[0, :n] - c["wav"]) ** 2)) <= WAV_RMS_TOL
+    assert np.abs(on - off).max() <= 1e-5
+
+
 def test_long_utterance_and_three_resident_voices(gpu_engine):
     """BASELINE config 5 shape: three voices (en V=46, de V=54, fr V=42) resident at
     once, interleaved calls; plus a long (400-id) sentence at 'low' quality:
