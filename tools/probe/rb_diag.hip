@@ -192,10 +192,12 @@ int main(int argc, char** argv) {
   const int C = CG_C;
   const int Ks[3] = {11, 7, 3};
   const int LMAX = CG_L * 8;
-  srand(2);
+  // (a generator of our own: rand() is shared with the HIP runtime's threads, which made the data differ from run to run)
+  unsigned long long lcg = 2;
+  auto rnd = [&]() { lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL; return (float)((lcg >> 40) & 0xFFFFFF) / 16777216.0f; };
   std::vector<float> x((size_t)C * LMAX);
   // activations shaped like the pipeline's (post leaky-ReLU residual stream): zero-mean, a few tenths
-  for (auto& v : x) v = (rand() / (float)RAND_MAX - 0.5f) * 0.6f;
+  for (auto& v : x) v = (rnd() - 0.5f) * 0.6f;
   for (size_t i = 0; i < x.size(); i += 7) x[i] = -x[i] * 3.f;  // (both signs of the leaky-ReLU)
   float* dx;
   CK(hipMalloc(&dx, x.size() * 4));
@@ -207,7 +209,7 @@ int main(int argc, char** argv) {
   for (int m = 0; m < 3; ++m) {
     const int K = Ks[m];
     std::vector<float> w((size_t)C * C * K), b(C);
-    for (auto& v : w) v = (rand() / (float)RAND_MAX - 0.5f) * 0.05f;
+    for (auto& v : w) v = (rnd() - 0.5f) * 0.05f;
     for (auto& v : b) v = 0.01f;
     PackedConv p = pack_conv(C, CG_MB * CG_WM, C, K, [&](int v) { return v; }, [&](int co, int ci, int k) { return w[((size_t)co * C + ci) * K + k]; },
                              [&](int co) { return b[co]; }, true, 8);
