@@ -626,4 +626,30 @@ for f in sorted(glob.glob("gpurun_out/r04_ab18/*.json")):
 PY
 }
 
+pmc_by_stage() {
+# SQ counters of the headline command with rb_group_kernel's dispatches split by launch geometry: the 256-channel stage (<= 1024
+# workgroups) and the 128-channel stage (> 1024), promotion on and off (off: conv_group_kernel runs the 256-channel stage)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_pmc_stage; mkdir -p $O
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 --no-config4 --no-config5 --no-half-mode --concurrency 1 --repeats 1 --no-steady-state"
+for v in new old; do
+  e=0; [ $v = old ] && e=1
+  MI355TTS_NO_GROUP_PROMOTE=$e timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $O/sq_$v -o sq --output-format csv -- $B > $O/sq_$v.log 2>&1
+  f=$(find $O/sq_$v -name "*counter_collection.csv" | head -1)
+  python tools/pmc_reduce.py $f --split-workgroups rb_group_kernel 1024 | grep -E "^kernel|rb_group|conv_group_kernel<11, 7, 3, 64, 2" > $O/by_stage_$v.csv
+  rm -rf $O/sq_$v
+done
+python - <<'PY'
+import csv, collections
+for v in ("old", "new"):
+    d = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f"gpurun_out/r04_pmc_stage/by_stage_{v}.csv")):
+        d[r["kernel"]][r["counter"]] = (int(r["dispatches"]), float(r["sum"]))
+    for k, c in d.items():
+        n, busy = c["SQ_VALU_MFMA_BUSY_CYCLES"]; gui = c["GRBM_GUI_ACTIVE"][1]
+        print(v, k, "dispatches", n, "MFMA busy %.3f" % (busy / (gui / 8 * 1024)), "active cycles per launch %.0f (per XCD)" % (gui / 8 / n),
+              "WAIT_INST_ANY/WAVE_CYCLES %.2f" % (c["SQ_WAIT_INST_ANY"][1] / c["SQ_WAVE_CYCLES"][1]))
+PY
+}
+
 "$@"
