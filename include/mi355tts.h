@@ -269,8 +269,13 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * for the 128-row tile's own threshold move to it when the dispatcher's round-robin deal of their (all resident) workgroups,
  * laid out as a snake, stays balanced (0 = they keep the 64 x 32 k-split tile: same results up to summation order);
  * "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
- * the call's worker; "glow_coalesce" (below).  The schedule options give the same bits under
- * every setting. */
+ * the call's worker; "wn_layer" (0 / 1 / 2, default 0: profiles/r05_wn_layer_ab.txt) — the WaveNet layers of the GlowTTS decoder (glow_tts/layers.py:138-162)
+ * as ONE column-owner launch each (wn_layer.h: gate conv + gate + res_skip conv on 16-column owners; the throughput form)
+ * instead of the gate16 + lin16 launches (the latency form): 0 = never, 2 = always, 1 = when the pass has at least
+ * "wn_layer_min_tiles" (default 48) 16-column tiles over its rows — padded batches, coalesced passes — or other calls hold
+ * workers of this context when the call starts; both forms compute the SAME BITS (same fragments, same chains, same order
+ * of the partial sums), so the choice may follow the load; "glow_coalesce" (below).  The schedule options give the same bits
+ * under every setting. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 /* Option "glow_coalesce" (0/1, default 0): concurrent batch-1 mi355tts_synthesize calls (the reference's per-sentence
  * thread pool, larynx/__init__.py:146-157, 187-190) share GlowTTS passes — the callers waiting when a pass starts become
@@ -282,6 +287,10 @@ int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
 int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
+/* Launches per kernel NAME since the last mi355tts_profile_reset, {"rb_group_kernel": n, ...}; counted whether profiling is
+ * on or not.  The class counters cannot tell a kernel from the fallback that would silently take its place (same launch count,
+ * same bits by design): the device tests assert on these.  No reference counterpart (measurement only). */
+int mi355tts_kernel_counts_json(mi355tts_ctx* ctx, char* buf, int cap);
 /* Median elapsed time (microseconds) of `pairs` EMPTY event pairs on an idle stream: what the two hipEventRecord calls around a
  * profiled launch add to its event-timed duration (rocprofv3's kernel durations do not contain it). */
 int mi355tts_profile_event_overhead(mi355tts_ctx* ctx, int pairs, double* us_out);

@@ -14,16 +14,48 @@ static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_
                                             "conv_mfma.glow_decoder",     "elementwise",
                                             "mrf_small.hifigan_narrow_stage"};
 
-// Host wait for a stream.  hipStreamSynchronize SPINS (a caller thread burns a core while its ~4 ms of kernels run, and 8 of
-// them contend with the launching threads for the runtime's locks); MI355TTS_SYNC_MODE=1 waits on a blocking event
-// (interrupt), =2 polls hipStreamQuery with a short sleep.  Read once.
+// Launches per kernel NAME since the last mi355tts_profile_reset (always counted: one relaxed atomic add per launch) —
+// mi355tts_kernel_counts_json.  The class counters above cannot tell a kernel from the fallback that would take its place
+// (rb_group_kernel -> conv_group_kernel, rb_pair_group_kernel -> pair_group_kernel, wn_layer_kernel -> gate16 + lin16:
+// same launch counts per class, same bits by design), so the device tests assert on these.
+enum KName {
+  KN_CONV_MFMA = 0, KN_CONV_M128, KN_CONV_GROUP, KN_RB_CONV, KN_RB_GROUP, KN_RB_GROUP_SNAKE, KN_PAIR, KN_PAIR_GROUP, KN_RB_PAIR,
+  KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_LIN16,
+  KN_LIN16_LN, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_COUNT
+};
+static const char* kname_name[KN_COUNT] = {
+    "conv_mfma_kernel", "conv_mfma_kernel.m128", "conv_group_kernel", "rb_conv_kernel", "rb_group_kernel", "rb_group_kernel.snake",
+    "resblock_pair_kernel", "pair_group_kernel", "rb_pair_kernel", "rb_pair_group_kernel", "conv_bf16_kernel", "conv_bf16_group_kernel",
+    "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "lin16_kernel", "lin16_kernel.ln",
+    "wn_layer_kernel", "wn_layer_kernel.gate_only", "glow_tail_kernel", "oproj_ln_kernel"};
+// the launch helpers without a context argument (launch_conv_k, launch_group_k) count through this: set by run_plan / run_group
+static thread_local std::atomic<long long>* g_kn = nullptr;
+static inline void kn_add(int k) {
+  if (g_kn) g_kn[k].fetch_add(1, std::memory_order_relaxed);
+}
+
+// Host wait for a stream.  hipStreamSynchronize SPINS: a caller thread burns a core for the ~4 ms its kernels run (28 ms of CPU
+// per utterance with eight callers, measured), and the reference's calling pattern is a ThreadPoolExecutor of up to 32 such
+// threads per process (larynx/__init__.py:66-67, :146) — times 8 ranks on a node.  Default (mode 3, adaptive): poll
+// hipStreamQuery without sleeping for the first 60 us (short waits: the frame-count read-back on an idle GPU, a warm vocoder tail),
+// then poll every ~20 us from nanosleep, with the calling thread's timer slack lowered to 1 us for the duration of the wait
+// (the default slack of 50 us would add that much to every wake-up) and restored afterwards.
+// MI355TTS_SYNC_MODE: 0 = hipStreamSynchronize, 1 = blocking event, 2 = query + 20 us sleep (no spin phase, default slack),
+// 3 = adaptive.  Read once.
 static hipError_t mi355_sync(hipStream_t s) {
-  static const int mode = [] { const char* e = std::getenv("MI355TTS_SYNC_MODE"); return e ? std::atoi(e) : 0; }();
+  static const int mode = [] { const char* e = std::getenv("MI355TTS_SYNC_MODE"); return e ? std::atoi(e) : 3; }();
   if (mode == 1) {
-    thread_local hipEvent_t ev = nullptr;
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return hipStreamSynchronize(s);
-    hipError_t e = hipEventRecord(ev, s);
-    return e == hipSuccess ? hipEventSynchronize(ev) : e;
+    // one blocking event per (thread, device): an event belongs to the device that was current when it was created
+    constexpr int MAXDEV = 16;
+    thread_local hipEvent_t evs[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return hipStreamSynchronize(s);
+    if (!evs[dev] && hipEventCreateWithFlags(&evs[dev], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+      evs[dev] = nullptr;
+      return hipStreamSynchronize(s);
+    }
+    hipError_t e = hipEventRecord(evs[dev], s);
+    return e == hipSuccess ? hipEventSynchronize(evs[dev]) : e;
   }
   if (mode == 2) {
     for (;;) {
@@ -32,6 +64,28 @@ static hipError_t mi355_sync(hipStream_t s) {
       struct timespec ts = {0, 20000};
       nanosleep(&ts, nullptr);
     }
+  }
+  if (mode == 3) {
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {  // spin phase
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 60000) break;
+    }
+    const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    if (slack > 1000) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    hipError_t e;
+    for (;;) {
+      e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) break;
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+    if (slack > 1000) prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+    return e;
   }
   return hipStreamSynchronize(s);
 }
@@ -56,6 +110,7 @@ struct Worker {
   // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
   // a mi355tts_set_option from another thread never changes a call's schedule half way through)
   bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true, o_group_promote = true;
+  bool o_wn_layer = false;  // this call's decoder runs its WaveNet layers as column-owner launches (wn_layer.h)
   // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
   // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
   hipStream_t gstream = nullptr;
@@ -84,6 +139,12 @@ struct mi355tts_ctx {
   // GlowTTS column-owner launches (coltile.h: block tails, conv_o + LayerNorm) AND the whole-tile-in-LDS convs of
   // gate16.h's lin16_kernel (FFN / duration predictor / prenet / 1 x 1 convs, LayerNorm prologues): 0 = the generic tiles
   std::atomic<bool> glow_fuse{true};
+  // GlowTTS decoder: one column-owner launch per WaveNet layer (wn_layer.h) — the throughput form; same bits as the
+  // gate16 + lin16 chain.  0 = never, 1 = when the pass is wide (>= wn_layer_min_tiles 16-column tiles: padded batches,
+  // coalesced passes) or other calls are in flight on the context, 2 = always.  Off by default: on MI355X the column owners
+  // lose under every load measured (a launch holds its hardware queue for its DURATION: profiles/r05_wn_layer_ab.txt)
+  std::atomic<int> wn_layer{0};
+  std::atomic<int> wn_layer_min_tiles{48};
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
@@ -110,6 +171,7 @@ struct mi355tts_ctx {
     long long launches = 0;
     double ms = 0, flop = 0;
   } prof[KC_COUNT];
+  std::atomic<long long> kn[KN_COUNT] = {};  // launches per kernel name (KName)
 };
 
 struct mi355tts_mel {

@@ -35,6 +35,7 @@ struct ProfScope {
 
 template <int K, int CI_C, int MB, int NB, int WN, int KS, int HALO, int EPI>
 static void launch_conv_inst(hipStream_t s, dim3 grid, const ConvArgs& a) {
+  kn_add(KN_CONV_MFMA);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, CI_C, MB, NB, WN, KS, HALO, EPI>), grid, dim3(64 * WN * KS), 0, s, a);
 }
 
@@ -77,6 +78,7 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
   if (a.x_ld % 4) return fail(MI355TTS_ERR_INVALID, "internal: activation row stride %d is not a multiple of 4", a.x_ld);
   if constexpr (EPI == EPI_LINEAR && K >= 3) {
     if (shape == TILE_M128) {
+      kn_add(KN_CONV_M128);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 1, 1, HALO, EPI, 4>), grid, dim3(256), 0, s, a);
       return 0;
     }
@@ -89,9 +91,13 @@ static int launch_conv_k(hipStream_t s, int MB, int shape, dim3 grid, const Conv
         if (!rb_off && g_rb_conv_on && a.Cin % 16 == 0 && !a.res && !a.accum && a.alpha == 1.0f) {
           if (a.x2 && a.x3) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<2, 4, EPI_UPSAMPLE, true>), grid, dim3(256), 0, s, a);
           else if (!a.x2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<2, 4, EPI_UPSAMPLE, false>), grid, dim3(256), 0, s, a);
-          if ((a.x2 && a.x3) || !a.x2) return 0;
+          if ((a.x2 && a.x3) || !a.x2) {
+            kn_add(KN_RB_CONV);
+            return 0;
+          }
         }
       }
+      kn_add(KN_CONV_M128);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_kernel<K, 16, 1, 2, 1, 1, HALO, EPI, 4>), grid, dim3(256), 0, s, a);
       return 0;
     }
@@ -295,7 +301,9 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   const dim3 grid = p.grid;
   int rc = 0;
   g_rb_conv_on = w->o_rb_conv;
+  g_kn = ctx->kn;
   if (p.bf16) {
+    kn_add(KN_CONV_BF16);
 #define BF16_LAUNCH_T(KK, TT)                                                                                                      \
   if (shape == BF_A) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 4, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a);      \
   else if (shape == BF_B) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_kernel<KK, 1, 1, 4, 1, ConvCfg<KK>::HALO, TT>), grid, dim3(256), 0, s, a); \
@@ -379,6 +387,7 @@ static void launch_group_inst(hipStream_t s, dim3 grid, const ConvGroupArgs& g) 
 }
 template <int K0, int K1, int K2>
 static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const ConvGroupArgs& g) {
+  kn_add(KN_CONV_GROUP);
   // the tile shapes the batch-1 ... batch-8 ResBlock launches of the shipped vocoders use
   if (shape == TILE_TINY && MB == 2) launch_group_inst<K0, K1, K2, 64, 2, 1, 1, 8>(s, grid, g);
   else if (shape == TILE_TINY && MB == 1) launch_group_inst<K0, K1, K2, 64, 1, 1, 1, 8>(s, grid, g);
@@ -388,7 +397,10 @@ static int launch_group_k(hipStream_t s, int MB, int shape, dim3 grid, const Con
   else if (shape == TILE_M128)  // 16-channel chunks, one time-wave: <= 128 VGPRs, four 4-wave workgroups per CU
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_group_kernel<K0, K1, K2, 16, 1, 2, 1, 1, ConvCfg<K0>::HALO, ConvCfg<K1>::HALO, ConvCfg<K2>::HALO, 4>),
                        grid, dim3(256), 0, s, g);
-  else return 1;
+  else {
+    if (g_kn) g_kn[KN_CONV_GROUP].fetch_sub(1, std::memory_order_relaxed);
+    return 1;
+  }
   return 0;
 }
 // Returns 0 = launched as one group, 1 = not groupable (caller launches the members one by one), < 0 = error.
@@ -487,8 +499,10 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   const dim3 grid(off_wg, 1, p0.grid.z);
   const int k0 = plans[ord[0]].K, k1 = plans[ord[1]].K, k2 = plans[ord[2]].K;
   const bool taps_ok = (k0 == 11 && k1 == 7 && k2 == 3) || (k0 == 7 && k1 == 5 && k2 == 3);
+  g_kn = ctx->kn;
   if (p0.bf16) {
     if (!taps_ok) return 1;
+    kn_add(KN_CONV_BF16_GROUP);
     ProfScope ps(ctx, w, p0.cls, flop, s);
 #define BF16_GROUP_T(KA, KB, KC, TT)                                                                                                                \
   if (p0.shape == BF_A)                                                                                                                            \
@@ -530,6 +544,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     if (rb_ok) {
       static const bool no_snake = [] { const char* e = std::getenv("MI355TTS_NO_SNAKE"); return e && std::atoi(e) != 0; }();
       if (grid.z == 1 && !no_snake) group_snake_order(g, ncu, 4 * ncu);  // four of these workgroups fit a CU (32 KB, <= 128 VGPRs)
+      kn_add(g.nseg ? KN_RB_GROUP_SNAKE : KN_RB_GROUP);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), grid, dim3(256), 0, s, g);
       return 0;
     }
@@ -615,6 +630,8 @@ static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t
   ProfScope ps(ctx, w, KC_RESBLOCK, p.flop, s);
   const PairArgs& a = p.a;
   const dim3 grid = p.grid;
+  g_kn = ctx->kn;
+  kn_add(p.bf16 ? KN_PAIR_BF16 : (w->o_rb_pair && p.rb) ? KN_RB_PAIR : KN_PAIR);
   if (p.bf16) {
 #define PAIR16_LAUNCH(KK, TT)                                                                                                                  \
   if (p.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_kernel<KK, 1, P16_WN32, P16_NB32, TT>), grid, dim3(64 * P16_WN32), 0, s, a);     \
@@ -682,6 +699,8 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   g.off[3] = off_wg;
   const dim3 grid(off_wg, 1, p0.grid.z);
   ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+  g_kn = ctx->kn;
+  kn_add(p0.bf16 ? KN_PAIR_BF16_GROUP : (w->o_rb_pair && p0.rb) ? KN_RB_PAIR_GROUP : KN_PAIR_GROUP);
   if (p0.bf16 == 3) {
     if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 1, P16_WN32, P16_NB32, 3>), grid, dim3(64 * P16_WN32), 0, s, g);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 2, P16_WN64, P16_NB64, 3>), grid, dim3(128 * P16_WN64), 0, s, g);
@@ -731,13 +750,16 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
   static const bool mrf8_off = [] { const char* e = std::getenv("MI355TTS_NO_MRF8"); return e && std::atoi(e) != 0; }();
   if (ms.C == 16) {
+    ctx->kn[KN_MRF_SMALL].fetch_add(1, std::memory_order_relaxed);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   } else if (!mrf8_off) {
     // 8 channels: the 4x4x1 16-block MFMA (no padding rows), its own fragment packing; two waves per tile
     a.w = arena + ms.w8_off;
     a.tab = reinterpret_cast<const int*>(arena + ms.t8_off);
+    ctx->kn[KN_MRF8].fetch_add(1, std::memory_order_relaxed);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf8_kernel<T, 3, 7, 11>), grid, dim3(128), 0, s, a);
   } else {
+    ctx->kn[KN_MRF_SMALL].fetch_add(1, std::memory_order_relaxed);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   }
   return 0;
@@ -783,6 +805,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   }
 #undef GATE16_J
 #undef GATE16_LAUNCH
+  ctx->kn[KN_GATE16].fetch_add(1, std::memory_order_relaxed);
   return 0;
 }
 
@@ -842,6 +865,42 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 1 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2>), grid, dim3(512), 0, s, g);
   else return 1;
+  ctx->kn[ln ? KN_LIN16_LN : KN_LIN16].fetch_add(1, std::memory_order_relaxed);
+  return 0;
+}
+
+// ---- one WaveNet layer of the GlowTTS decoder as ONE column-owner launch (wn_layer.h): gate conv `in` + gate + res_skip conv
+// `rs` (rs == nullptr: the block's last layer — its res_skip runs in glow_tail_kernel — writes the gated activations to `acts`).
+// Returns 1 when the shapes are not the kernel's (the caller runs gate16 + lin16), 0 when launched.  Same bits as those two.
+static bool wn_layer_shape_ok(const DevConv& in, const DevConv* rs, int H) {
+  if (in.g16_J != 6 || H != 192 || in.Cin != H || (in.K != 5 && in.K != 3)) return false;
+  if (rs && (rs->l16_J != 6 || rs->K != 1 || rs->Cin != H || rs->Cout != 2 * H)) return false;
+  return true;
+}
+static int run_wn_layer(mi355tts_ctx* ctx, Worker* w, const DevConv& in, const DevConv* rs, const float* arena, const float* x, float* x_out,
+                        float* acts, float* skip, int accum, long long bs, int ld, const int* len, int host_len, int dil, int pad,
+                        const float* cond, long long cond_bs, int H, int B, int n_max) {
+  if (!wn_layer_shape_ok(in, rs, H) || dil != 1 || pad != (in.K - 1) / 2 || ld % 4 || n_max <= 0 || x == x_out) return 1;
+  WnLayerArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.x_out = x_out; a.bs = bs; a.ld = ld;
+  if (B == 1 && host_len >= 0) { a.len = nullptr; a.len_const = host_len; } else { a.len = len; }
+  a.len_mul = 1;
+  a.gw = in.g16_w; a.gb = in.g16_b;
+  if (rs) { a.rw = arena + rs->l16_w_off; a.rb = arena + rs->l16_b_off; }
+  a.acts = acts; a.skip = skip; a.accum = accum; a.pad = pad; a.cond = cond; a.cond_bs = cond_bs;
+  const double mac = (double)in.Cout * in.Cin * in.K + (rs ? (double)rs->Cout * rs->Cin : 0.0);
+  ProfScope ps(ctx, w, KC_GLOW_DEC_CONV, 2.0 * mac * (double)n_max * B);
+  const dim3 grid((n_max + WN_T - 1) / WN_T, B);
+  hipStream_t s = w->stream;
+  ctx->kn[rs ? KN_WN_LAYER : KN_WN_GATE].fetch_add(1, std::memory_order_relaxed);
+  if (in.K == 5) {
+    if (rs) hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<5, 6, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<5, 6, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (rs) hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<3, 6, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<3, 6, false>), grid, dim3(256), 0, s, a);
+  }
   return 0;
 }
 

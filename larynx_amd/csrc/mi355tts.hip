@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <time.h>
+#include <sys/prctl.h>
 #include <atomic>
 #include <condition_variable>
 #include <cmath>
@@ -35,6 +36,7 @@
 #include "mrf_small.h"
 #include "gate16.h"
 #include "coltile.h"
+#include "wn_layer.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -1247,6 +1249,14 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->glow_priority = value;
     return 0;
   }
+  if (std::strcmp(name, "wn_layer") == 0) {
+    ctx->wn_layer = value;
+    return 0;
+  }
+  if (std::strcmp(name, "wn_layer_min_tiles") == 0) {
+    ctx->wn_layer_min_tiles = value;
+    return 0;
+  }
   if (std::strcmp(name, "serial_branches") == 0) {
     ctx->serial_branches = value != 0;
     return 0;
@@ -1264,6 +1274,21 @@ extern "C" int mi355tts_profile_reset(mi355tts_ctx* ctx) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& a : ctx->prof) a = mi355tts_ctx::Acc();
+  for (auto& k : ctx->kn) k.store(0, std::memory_order_relaxed);
+  return 0;
+}
+// {"kernel name": launches, ...} since the last mi355tts_profile_reset — counted whether profiling is on or not
+extern "C" int mi355tts_kernel_counts_json(mi355tts_ctx* ctx, char* buf, int cap) {
+  if (!ctx || !buf || cap <= 2) return fail(MI355TTS_ERR_INVALID, "bad argument");
+  std::string s = "{";
+  for (int i = 0; i < KN_COUNT; ++i) {
+    char tmp[128];
+    std::snprintf(tmp, sizeof(tmp), "%s\"%s\": %lld", i ? ", " : "", kname_name[i], ctx->kn[i].load(std::memory_order_relaxed));
+    s += tmp;
+  }
+  s += "}";
+  if ((int)s.size() + 1 > cap) return fail(MI355TTS_ERR_TOO_SMALL, "kernel-count buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
   return 0;
 }
 // What the two event records of a ProfScope cost by themselves: `pairs` empty pairs (hipEventRecord a, hipEventRecord b,

@@ -449,3 +449,9 @@ class Engine:
         buf = C.create_string_buffer(4096)
         ffi.check(self.lib, self.lib.mi355tts_profile_json(self._ctx, buf, 4096))
         return json.loads(buf.value.decode("ascii"))
+
+    def kernel_counts(self) -> dict:
+        """Launches per kernel name since the last `profile_reset` (`mi355tts_kernel_counts_json`; always counted)."""
+        buf = C.create_string_buffer(4096)
+        ffi.check(self.lib, self.lib.mi355tts_kernel_counts_json(self._ctx, buf, 4096))
+        return json.loads(buf.value.decode("ascii"))

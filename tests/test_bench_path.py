@@ -1,7 +1,7 @@
 """bench.py's own code path — self-spawn under torch.distributed.run, weight
 broadcast, weak-scaling headline region, BASELINE config 3 (LPT shards + ordered
-gather) — at world size 2 over gloo on the CPU emulator build with shrunk
-hyper-parameters.  The same script, flags aside, is what the driver runs on GPUs."""
+gather) — at world sizes 2 AND 8 (the size the driver's scaling run ends at) over gloo on the CPU emulator build with
+shrunk hyper-parameters.  The same script, flags aside, is what the driver runs on GPUs."""
 import json
 import subprocess
 import sys
@@ -12,20 +12,20 @@ import pytest
 REPO = Path(__file__).resolve().parent.parent
 
 
-def _run(emu_library, gpus):
+def _run(emu_library, gpus, utterances=7):
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--ids", "12",
-           "--concurrency", "2", "--repeats", "2", "--config3-utterances", "7", "--device", "cpu", "--library", str(emu_library),
+           "--concurrency", "2", "--repeats", "2", "--config3-utterances", str(utterances), "--device", "cpu", "--library", str(emu_library),
            "--tiny", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(REPO))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=str(REPO))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout  # rank 0 prints ONE JSON line
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
-def test_bench_line_at_world_size(emu_library_path, gpus):
-    out = _run(emu_library_path, gpus)
+@pytest.mark.parametrize("gpus,utterances", [(1, 7), (2, 7), (8, 19)])
+def test_bench_line_at_world_size(emu_library_path, gpus, utterances):
+    out = _run(emu_library_path, gpus, utterances)
     assert out["n_gpus"] == gpus and out["steps"] == 3 and out["warmup"] == 1
     assert out["metric"] == "utterances_per_sec" and out["unit"] == "utterances/s" and out["higher_is_better"] is True
     assert out["scaling"] == "weak" and out["value"] > 0 and out["ms_per_step"] > 0
@@ -34,6 +34,8 @@ def test_bench_line_at_world_size(emu_library_path, gpus):
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["launches"] > 0 and "grouped launch" in rf["schedule"]
     c3 = out["config3"]
-    assert c3["utterances"] == 7 and c3["scaling"] == "strong" and sum(c3["shard_sizes"]) == 7 and len(c3["shard_sizes"]) == gpus
+    assert c3["utterances"] == utterances and c3["scaling"] == "strong" and sum(c3["shard_sizes"]) == utterances
+    assert len(c3["shard_sizes"]) == gpus and min(c3["shard_sizes"]) >= 1
+    assert len(out["per_rank"]["utterances_per_sec"]) == gpus
     assert c3["utterances_per_sec"] > 0 and c3["audio_seconds"] > 0
     assert out["denoiser_on"] is None  # the emulator's tiny vocoder (hop 8) is below the denoiser's STFT size

@@ -340,19 +340,64 @@ def test_glowtts_launch_counts_on_the_device(gpu_engine):
         prof = gpu_engine.profile()
     finally:
         gpu_engine.set_profiling(False)
+        names = gpu_engine.kernel_counts()
     hp = HP.LJSPEECH
+    # by kernel name: the 16-row gate tile, the block tails and conv_o + LayerNorm as column owners; no generic-tile fallback
+    assert names["gate16_kernel"] == hp.n_blocks_dec * hp.n_block_layers and names["glow_tail_kernel"] == hp.n_blocks_dec
+    assert names["oproj_ln_kernel"] == hp.n_layers_enc and names["wn_layer_kernel"] == 0
+    assert names["lin16_kernel"] + names["lin16_kernel.ln"] >= hp.n_blocks_dec * (hp.n_block_layers - 1) + 2 * hp.n_layers_enc
     assert prof["conv_mfma.glow_decoder"]["launches"] == 1 + hp.n_blocks_dec * (2 * hp.n_block_layers)
     assert prof["conv_mfma.glow_encoder"]["launches"] == 4 + hp.n_layers_enc * 4 + 3
     assert prof["elementwise"]["launches"] == 1 + hp.n_layers_enc + 5
 
 
+VOC_KERNELS = {
+    # 'high' at 617 frames, batch 1: the 256-channel stage's six launches are the PROMOTED ones (128-row tile, snake dispatch
+    # order), the 128-channel stage's six keep the plain longest-first order (more workgroups than resident slots), the 64- and
+    # 32-channel stages run the four-wave fused pair; nothing falls back to the chunked tile or the k-split pair
+    "high": {"rb_group_kernel.snake": 6, "rb_group_kernel": 6, "rb_pair_group_kernel": 6, "conv_group_kernel": 0, "pair_group_kernel": 0,
+             "mrf_small_kernel": 0, "mrf8_kernel": 0},
+    # 'medium': 42 / 161 tiles per member in its 64- / 32-channel stages -> the 8-wave k-split pair (plan_pair's rule); the 16-
+    # and 8-channel stages are one launch each
+    "medium": {"pair_group_kernel": 6, "rb_pair_group_kernel": 0, "rb_group_kernel": 0, "rb_group_kernel.snake": 0, "conv_group_kernel": 0,
+               "mrf_small_kernel": 1, "mrf8_kernel": 1},
+}
+
+
+def test_wavenet_layer_column_owner_form_computes_the_same_bits(gpu_engine):
+    """csrc/wn_layer.h (option `wn_layer`; off by default: profiles/r05_wn_layer_ab.txt): one column-owner launch per WaveNet
+    layer promises the SAME BITS as gate16_kernel + lin16_kernel on the real matrix pipes — the standard utterance with the
+    device's noise, and a ragged batch of eight."""
+    (gsd, g), _ = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    rng = np.random.default_rng(11)
+    one = synthetic.synthetic_phoneme_ids(rng, 120, HP.LJSPEECH.num_symbols)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in (19, 26, 31, 33, 64, 47, 90, 120)]
+    hp = HP.LJSPEECH
+    for x in (one, rows):
+        got = {}
+        for form in (2, 0):
+            gpu_engine.set_option("wn_layer", form)
+            try:
+                gpu_engine.profile_reset()
+                mel = gpu_engine.glow_infer(g, x, 0.667, 0.65, seed=5)
+                got[form] = (mel.numpy("raw").copy(), list(mel.frames), gpu_engine.kernel_counts())
+                mel.free()
+            finally:
+                gpu_engine.set_option("wn_layer", 0)
+        assert got[2][2]["wn_layer_kernel"] == hp.n_blocks_dec * (hp.n_block_layers - 1) and got[2][2]["gate16_kernel"] == 0
+        assert got[2][2]["wn_layer_kernel.gate_only"] == hp.n_blocks_dec
+        assert got[0][2]["wn_layer_kernel"] == 0 and got[0][2]["gate16_kernel"] == hp.n_blocks_dec * hp.n_block_layers
+        assert got[2][1] == got[0][1]
+        assert np.array_equal(got[2][0], got[0][0])
+
+
 @pytest.mark.parametrize("quality,resblock,narrow", [("high", 18, 0), ("medium", 6, 2)])
 def test_vocoder_launch_counts_on_the_device(gpu_engine, quality, resblock, narrow):
-    """The fused vocoder schedule is the one that runs at the released shapes: 'high' = 18 grouped ResBlock launches (two wide
-    stages x 3 dilation steps x 2 convs as `conv_group_kernel`, two fused-pair stages x 3 steps as `pair_group_kernel`);
-    'medium' = 6 fused-pair launches + ONE `mrf_small_kernel` / `mrf8_kernel` launch for each of its two narrow stages.  A
-    silent fallback to the generic tiles (54 ResBlock launches for 'high'; no narrow-stage class for 'medium') would still
-    pass every value check."""
+    """The fused vocoder schedule is the one that runs at the released shapes, by launch CLASS ('high' = 18 grouped ResBlock
+    launches, 'medium' = 6 fused-pair launches + one launch per narrow stage) and by kernel NAME (`kernel_counts`): the class
+    counts cannot tell `rb_group_kernel` from `conv_group_kernel` or `rb_pair_group_kernel` from `pair_group_kernel` — same
+    launch count, and the first pair computes the same bits by design — so a tile rule that misfired would pass every value
+    check and the class counts."""
     vhp = HP.VOCODER_QUALITY[quality]
     _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, vhp)
     rng = np.random.default_rng(5)
@@ -364,11 +409,14 @@ def test_vocoder_launch_counts_on_the_device(gpu_engine, quality, resblock, narr
         gpu_engine.profile_reset()
         gpu_engine.hifigan_infer(v, mb)
         prof = gpu_engine.profile()
+        names = gpu_engine.kernel_counts()
     finally:
         gpu_engine.set_profiling(False)
     assert prof["conv_mfma.hifigan_resblock"]["launches"] == resblock, prof
     assert prof.get("mrf_small.hifigan_narrow_stage", {"launches": 0})["launches"] == narrow, prof
     assert prof["conv_mfma.hifigan_upsample"]["launches"] == 4 and prof["conv_mfma.hifigan_pre_post"]["launches"] == 2, prof
+    for k, n in VOC_KERNELS[quality].items():
+        assert names[k] == n, (k, names)
 
 
 def test_promoted_stage_really_runs_on_the_device(gpu_engine):
