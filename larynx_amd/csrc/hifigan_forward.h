@@ -112,7 +112,7 @@ static HifiLayout hifi_layout(const mi355tts_hifigan_hparams& h, int hop, int B,
   for (int i = 0; i < L.nbuf; ++i) L.o_buf[i] = cv.take(sizeof(float) * (size_t)B * L.plane);
   L.o_wav = cv.take(sizeof(float) * (size_t)B * L.Nld);
   L.o_i16 = cv.take(sizeof(short) * (size_t)B * (L.Nld + (size_t)pads));
-  L.o_peak = cv.take(sizeof(unsigned) * B);
+  L.o_peak = cv.take(sizeof(float) * (size_t)B * (L.Nld / POST_TW + 2));  // post_conv_kernel's per-workgroup maxima of every row
   L.Tmax = denoise ? (int)((N - DN_FFT + DN_HOP - 1) / DN_HOP) : 0;
   L.o_wav2 = cv.take(denoise ? sizeof(float) * (size_t)B * L.Nld : 0);
   L.o_fbuf = cv.take(denoise ? sizeof(float) * (size_t)B * L.Tmax * DN_FFT : 0);
@@ -432,7 +432,43 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     Lin = Lout;
     ldin = ldo;
   }
-  {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
+  // Option "voc_out" (default 1): conv_post + tanh + the rows' peaks in ONE dedicated launch and the delivery of the rows in one
+  // more (voc_out.h); 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per piece of every row.
+  static const bool voc_out_off = [] { const char* e = std::getenv("MI355TTS_NO_VOC_OUT"); return e && std::atoi(e) != 0; }();
+  const bool vo = !voc_out_off && ctx->voc_out.load() && hm->post_C == ch && hm->post.K == 7 && ldin % 4 == 0;
+  const long long peak_ld = (long long)(Nld / POST_TW + 2);
+  bool peak_parts_ready = false;  // post_conv_kernel left the per-workgroup maxima of the FINAL waveform
+  if (vo) {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
+    PostArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = cur[0];
+    if (ncur > 1) {
+      a.x2 = cur[1];
+      a.x3 = ncur > 2 ? cur[2] : nullptr;
+    }
+    a.in_div = cur_div;
+    a.slope = 0.01f;
+    a.x_bs = (long long)ch * ldin;
+    a.x_ld = ldin;
+    if (B == 1 && voc_host_len >= 0) { a.len = nullptr; a.len_const = voc_host_len * mul; } else { a.len = d_frames; }
+    a.len_mul = mul;
+    a.w = hm->arena + hm->post_w_off;
+    a.bias = hm->arena + hm->post_b_off;
+    a.C = ch;
+    a.y = wav;
+    a.y_bs = (long long)Nld;
+    if (wav_i16 && !denoise) {
+      a.peak = reinterpret_cast<float*>(peak);
+      a.peak_ld = peak_ld;
+      peak_parts_ready = true;
+    }
+    ProfScope ps(ctx, w, KC_VOC_IO, 2.0 * (double)ch * 7 * (double)Lin * B);
+    ctx->kn[KN_POST_CONV].fetch_add(1, std::memory_order_relaxed);
+    const dim3 pg((Lin + POST_TW - 1) / POST_TW, B);
+    if (a.x3) hipLaunchKernelGGL(HIP_KERNEL_NAME(post_conv_kernel<7, 3>), pg, dim3(256), 0, s, a);
+    else if (a.x2) hipLaunchKernelGGL(HIP_KERNEL_NAME(post_conv_kernel<7, 2>), pg, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(post_conv_kernel<7, 1>), pg, dim3(256), 0, s, a);
+  } else {
     ConvArgs a = base_args(cur[0], (long long)ch * ldin, ldin, d_frames, mul, wav, (long long)Nld, (int)Nld, d_frames, mul, 1, 3);
     set_inputs(a);
     a.in_slope = 0.01f;
@@ -451,34 +487,69 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   }
   const size_t ild = Nld + (size_t)pads;  // row stride of the int16 staging buffer
   const long long rowlen = (long long)pad0 + N + call.pad_after;  // samples delivered per row (then zeros up to wav_ld)
-  {
+  if (vo) {
+    // ONE launch delivers the rows: to the caller's device buffers (pause before | samples | zeros up to the row stride), or to
+    // the staging buffers the host copy reads (the float rows in place: zero tails behind a short row's samples)
     ProfScope ps(ctx, w, KC_SMALL, 0);
-    hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
-    if (wav_i16) {
+    if (wav_i16 && !peak_parts_ready) {  // behind the denoiser: one peak per row, from the denoised rows
       HIPCHECK(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
       hipLaunchKernelGGL(absmax_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak);
-      hipLaunchKernelGGL(to_int16_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak, i16,
-                         (long long)ild, (long long)ild, pad0);
     }
-  }
-  if (out_dev) {
-    for (int b = 0; b < B; ++b) {
-      if (wav_f32) {
-        float* dst = wav_f32 + (size_t)b * wav_ld;
-        if (pad0) HIPCHECK(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)pad0, s));
-        HIPCHECK(hipMemcpyAsync(dst + pad0, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, s));
-        if (wav_ld > pad0 + N) HIPCHECK(hipMemsetAsync(dst + pad0 + N, 0, sizeof(float) * (size_t)(wav_ld - pad0 - N), s));
-      }
+    WaveOutArgs o;
+    std::memset(&o, 0, sizeof(o));
+    o.wav = wav; o.bs = (long long)Nld; o.frames = d_frames; o.hop = hop;
+    o.peak = reinterpret_cast<const float*>(peak);
+    o.peak_ld = peak_parts_ready ? peak_ld : 1;
+    o.peak_parts = peak_parts_ready ? 0 : 1;
+    o.pad_before = pad0;
+    if (out_dev) {
+      if (wav_f32) { o.f32 = wav_f32; o.f_bs = wav_ld; o.f_ld = wav_ld; }
+      if (wav_i16) { o.i16 = wav_i16; o.i_bs = wav_ld; o.i_ld = wav_ld; }
+    } else {
+      // (the float rows stay where they are: only a short row's tail up to the longest row is zeroed, in place)
+      if (wav_i16) { o.i16 = i16; o.i_bs = (long long)ild; o.i_ld = (long long)ild; }
+    }
+    if (o.f32 || o.i16) {
+      ctx->kn[KN_WAVE_OUT].fetch_add(1, std::memory_order_relaxed);
+      hipLaunchKernelGGL(wave_out_kernel, dim3(128, B), dim3(256), 0, s, o);
+    }
+    if (!out_dev && wav_f32 && B > 1) hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
+    if (out_dev) {
+      HIPCHECK(mi355_sync(s));
+      HIPCHECK(hipGetLastError());
+      drain.ok = true;
+      return 0;
+    }
+  } else {
+    {
+      ProfScope ps(ctx, w, KC_SMALL, 0);
+      hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
       if (wav_i16) {
-        int16_t* dst = wav_i16 + (size_t)b * wav_ld;
-        HIPCHECK(hipMemcpyAsync(dst, i16 + (size_t)b * ild, sizeof(short) * (size_t)rowlen, hipMemcpyDeviceToDevice, s));
-        if (wav_ld > rowlen) HIPCHECK(hipMemsetAsync(dst + rowlen, 0, sizeof(short) * (size_t)(wav_ld - rowlen), s));
+        HIPCHECK(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
+        hipLaunchKernelGGL(absmax_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak);
+        hipLaunchKernelGGL(to_int16_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak, i16,
+                           (long long)ild, (long long)ild, pad0);
       }
     }
-    HIPCHECK(mi355_sync(s));
-    HIPCHECK(hipGetLastError());
-    drain.ok = true;
-    return 0;
+    if (out_dev) {
+      for (int b = 0; b < B; ++b) {
+        if (wav_f32) {
+          float* dst = wav_f32 + (size_t)b * wav_ld;
+          if (pad0) HIPCHECK(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)pad0, s));
+          HIPCHECK(hipMemcpyAsync(dst + pad0, wav + (size_t)b * Nld, sizeof(float) * (size_t)N, hipMemcpyDeviceToDevice, s));
+          if (wav_ld > pad0 + N) HIPCHECK(hipMemsetAsync(dst + pad0 + N, 0, sizeof(float) * (size_t)(wav_ld - pad0 - N), s));
+        }
+        if (wav_i16) {
+          int16_t* dst = wav_i16 + (size_t)b * wav_ld;
+          HIPCHECK(hipMemcpyAsync(dst, i16 + (size_t)b * ild, sizeof(short) * (size_t)rowlen, hipMemcpyDeviceToDevice, s));
+          if (wav_ld > rowlen) HIPCHECK(hipMemsetAsync(dst + rowlen, 0, sizeof(short) * (size_t)(wav_ld - rowlen), s));
+        }
+      }
+      HIPCHECK(mi355_sync(s));
+      HIPCHECK(hipGetLastError());
+      drain.ok = true;
+      return 0;
+    }
   }
   // host outputs: device -> the worker's pinned staging (async DMA) -> the caller's (pageable)
   // buffers; a pageable destination would make every hipMemcpyAsync a blocking staged copy

@@ -21,13 +21,13 @@ static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_
 enum KName {
   KN_CONV_MFMA = 0, KN_CONV_M128, KN_CONV_GROUP, KN_RB_CONV, KN_RB_GROUP, KN_RB_GROUP_SNAKE, KN_PAIR, KN_PAIR_GROUP, KN_RB_PAIR,
   KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_LIN16,
-  KN_LIN16_LN, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_COUNT
+  KN_LIN16_LN, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_COUNT
 };
 static const char* kname_name[KN_COUNT] = {
     "conv_mfma_kernel", "conv_mfma_kernel.m128", "conv_group_kernel", "rb_conv_kernel", "rb_group_kernel", "rb_group_kernel.snake",
     "resblock_pair_kernel", "pair_group_kernel", "rb_pair_kernel", "rb_pair_group_kernel", "conv_bf16_kernel", "conv_bf16_group_kernel",
     "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "lin16_kernel", "lin16_kernel.ln",
-    "wn_layer_kernel", "wn_layer_kernel.gate_only", "glow_tail_kernel", "oproj_ln_kernel"};
+    "wn_layer_kernel", "wn_layer_kernel.gate_only", "glow_tail_kernel", "oproj_ln_kernel", "post_conv_kernel", "wave_out_kernel"};
 // the launch helpers without a context argument (launch_conv_k, launch_group_k) count through this: set by run_plan / run_group
 static thread_local std::atomic<long long>* g_kn = nullptr;
 static inline void kn_add(int k) {
@@ -115,6 +115,7 @@ struct Worker {
   // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
   hipStream_t gstream = nullptr;
   hipEvent_t ev_glow = nullptr;
+  int gprio = 0;  // the option value gstream was created for (1 = highest, 2 = lowest priority)
 };
 
 struct mi355tts_ctx {
@@ -145,6 +146,7 @@ struct mi355tts_ctx {
   // lose under every load measured (a launch holds its hardware queue for its DURATION: profiles/r05_wn_layer_ab.txt)
   std::atomic<int> wn_layer{0};
   std::atomic<int> wn_layer_min_tiles{48};
+  std::atomic<bool> voc_out{true};    // conv_post + peak and the delivery of the rows as two dedicated launches (voc_out.h); 0 = round 4's ten
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
@@ -185,6 +187,18 @@ struct mi355tts_mel {
   size_t raw_bytes = 0;  // allocation size of raw / voc (pool bookkeeping)
 };
 
+// The kernel-selection options as a call sees them: taken when the call checks its worker out, so EVERY entry point (the op /
+// bench entry points and the denoiser bias too, not only glow_run / hifigan_run) launches under the context's current options
+// and never under what the worker's previous call left behind.
+static void snapshot_options(mi355tts_ctx* ctx, Worker* w) {
+  w->o_glow_fuse = ctx->glow_fuse.load();
+  w->o_gate16 = ctx->gate16.load();
+  w->o_rb_conv = ctx->rb_conv.load();
+  w->o_rb_pair = ctx->rb_pair.load();
+  w->o_group_promote = ctx->group_promote.load();
+  w->o_wn_layer = false;
+}
+
 static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -193,6 +207,7 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
       ctx->free_workers.pop_back();
       (*out)->arena_pos = 0;
       (*out)->flop_scale = 1.0;
+      snapshot_options(ctx, *out);
       ctx->active_calls.fetch_add(1, std::memory_order_relaxed);
       return 0;
     }
@@ -216,6 +231,7 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
     ctx->all_workers.push_back(w);
   }
   ctx->active_calls.fetch_add(1, std::memory_order_relaxed);
+  snapshot_options(ctx, w);
   *out = w;
   return 0;
 }

@@ -259,6 +259,8 @@ struct HifiModel {
   uint16_t* arena16 = nullptr;  // split-bf16 weight fragments of the ResBlock convs
   std::atomic<int> precision{0};  // 0 = exact f32 MFMA, 1 = split-bf16 (3 x bf16 MFMA) for the wide ResBlock convs
   DevConv pre, post;
+  size_t post_w_off = 0, post_b_off = 0;  // conv_post's raw [C][7] weight and bias (post_conv_kernel)
+  int post_C = 0;
   std::vector<DevConv> ups;
   // [stage][kernel][dilation index]
   std::vector<std::vector<std::vector<HifiResConv>>> rb;

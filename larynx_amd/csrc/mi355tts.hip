@@ -37,6 +37,7 @@
 #include "gate16.h"
 #include "coltile.h"
 #include "wn_layer.h"
+#include "voc_out.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
 
@@ -552,6 +553,9 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     TAKE(w, std::string("conv_post.weight"), (int64_t)ch * 7);
     TAKE(b, std::string("conv_post.bias"), 1);
     hm->post = add_conv(ab, w, b, 1, ch, 7, ROWS_PLAIN);
+    hm->post_w_off = ab.add(w, (size_t)ch * 7);  // raw [C][7] + bias for post_conv_kernel (voc_out.h)
+    hm->post_b_off = ab.add(b, 1);
+    hm->post_C = ch;
   }
 #undef TAKE
   CHECK(upload_arena(ctx, ab, &hm->arena));
@@ -875,13 +879,37 @@ static int synthesize_impl(mi355tts_ctx* ctx, int glow, int vocoder, const int64
     return hifigan_run(ctx, w, hm, &view, v);
   }
   mi355tts_mel* mel = nullptr;
+  struct MelDrop {
+    Worker* w;
+    mi355tts_mel* m;
+    ~MelDrop() {
+      if (!m) return;
+      mi355_sync(w->stream);  // its blocks go back to the pool: nothing queued may still read them
+      mel_destroy(m);
+    }
+  } drop{w, nullptr};
   const int gprio = ctx->glow_priority.load();
   if (gprio) {
+    if (w->gstream && w->gprio != gprio) {  // the option changed since this worker's stream was made: recreate it
+      mi355_sync(w->gstream);
+      hipStreamDestroy(w->gstream);
+      w->gstream = nullptr;
+    }
     if (!w->gstream) {
       int least = 0, greatest = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIPCHECK(hipStreamCreateWithPriority(&w->gstream, hipStreamNonBlocking, gprio == 2 ? least : greatest));
-      HIPCHECK(hipEventCreateWithFlags(&w->ev_glow, hipEventDisableTiming));
+      hipStream_t gs = nullptr;
+      HIPCHECK(hipStreamCreateWithPriority(&gs, hipStreamNonBlocking, gprio == 2 ? least : greatest));
+      if (!w->ev_glow) {
+        const hipError_t e = hipEventCreateWithFlags(&w->ev_glow, hipEventDisableTiming);
+        if (e != hipSuccess) {  // stream and event exist together or not at all
+          w->ev_glow = nullptr;
+          hipStreamDestroy(gs);
+          return fail(MI355TTS_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+      }
+      w->gstream = gs;
+      w->gprio = gprio;
     }
     hipStream_t bulk = w->stream;
     w->stream = w->gstream;  // the worker belongs to this call: everything glow_run queues goes to the priority stream
@@ -891,19 +919,17 @@ static int synthesize_impl(mi355tts_ctx* ctx, int glow, int vocoder, const int64
       mi355_sync(w->gstream);
       return rc;
     }
-    HIPCHECK(hipEventRecord(w->ev_glow, w->gstream));
-    HIPCHECK(hipStreamWaitEvent(bulk, w->ev_glow, 0));
+    drop.m = mel;  // from here on every exit frees the mel (after draining the bulk stream)
+    hipError_t e = hipEventRecord(w->ev_glow, w->gstream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(bulk, w->ev_glow, 0);
+    if (e != hipSuccess) {
+      mi355_sync(w->gstream);  // the mel's producers run on the priority stream, which MelDrop does not drain
+      return fail(MI355TTS_ERR_HIP, "glow_priority hand-over: %s", hipGetErrorString(e));
+    }
   } else {
     CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
+    drop.m = mel;
   }
-  struct MelDrop {
-    Worker* w;
-    mi355tts_mel* m;
-    ~MelDrop() {
-      mi355_sync(w->stream);  // its blocks go back to the pool: nothing queued may still read them
-      mel_destroy(m);
-    }
-  } drop{w, mel};
   for (int b = 0; b < B; ++b) frames_out[b] = mel->frames[b];
   CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), B, mel->M, mel->max_frames, v));
   return hifigan_run(ctx, w, hm, mel, v);
@@ -1247,6 +1273,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "glow_priority") == 0) {
     ctx->glow_priority = value;
+    return 0;
+  }
+  if (std::strcmp(name, "voc_out") == 0) {
+    ctx->voc_out = value != 0;
     return 0;
   }
   if (std::strcmp(name, "wn_layer") == 0) {

@@ -53,6 +53,7 @@ class GlowHParams:
             m.get("hidden_channels_dec", hid) or hid
         ) != hid:
             raise ValueError("hidden_channels_enc/dec must equal hidden_channels")
+        # `"n_speakers": null` (some exported configs) and 0 both mean what the reference's default of 1 means: no embedding
         n_spk = int(m.get("n_speakers", 1) or 0)
         gin = int(m.get("gin_channels", 0) or 0)
         if n_spk > 1 and gin <= 0:

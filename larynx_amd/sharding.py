@@ -79,8 +79,10 @@ def micro_batches(indices: typing.Sequence[int], lengths: typing.Sequence[int], 
 
 def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[np.ndarray], rank: int, world: int,
                      noise_scale: float = 0.667, length_scale: float = 1.0, seed: int = 0, audio_settings=None,
-                     batch: int = 1) -> typing.Dict[int, np.ndarray]:
+                     batch: int = 1, speaker_ids: typing.Optional[typing.Sequence[int]] = None) -> typing.Dict[int, np.ndarray]:
     """This rank's share of the work list -> {utterance index: int16 audio}.
+    `speaker_ids`: a multi-speaker voice's speaker per UTTERANCE (indexed like `id_rows` and the seeds; the reference's
+    `speaker_id` setting, larynx/glow_tts.py:116-130) — required for such a voice, an error for a single-speaker one.
     `batch` > 1 runs length-bucketed micro-batches through one pair of calls each.  The
     kernels mask by row length and the device RNG stream of a row is keyed by the UTTERANCE
     (`seed + utterance index`, `mi355tts_glow_infer_rows`), so every utterance draws the noise
@@ -88,13 +90,16 @@ def synthesize_shard(engine, glow: int, vocoder: int, id_rows: typing.Sequence[n
     in.  The audio is then equal to the single call's UP TO f32 SUMMATION ORDER (a padded batch
     picks other tile shapes than a batch-1 launch: +-1 int16 LSB in the tests), not bit for bit."""
     lengths = [len(r) for r in id_rows]
+    if speaker_ids is not None and len(speaker_ids) != len(id_rows):
+        raise ValueError("speaker_ids: one speaker per utterance of the work list")
     mine = lpt_assign(lengths, world)[rank]
     out: typing.Dict[int, np.ndarray] = {}
     hop = engine.hop(vocoder)
     for group in micro_batches(mine, lengths, batch):
         rows = [np.asarray(id_rows[i], np.int64) for i in group]
         mel = engine.glow_infer(glow, rows if len(rows) > 1 else rows[0], noise_scale, length_scale,
-                                row_seeds=[seed + i for i in group], audio_settings=audio_settings)
+                                row_seeds=[seed + i for i in group], audio_settings=audio_settings,
+                                speaker_ids=None if speaker_ids is None else [int(speaker_ids[i]) for i in group])
         _, i16 = engine.hifigan_infer(vocoder, mel, want_float=False)
         for b, i in enumerate(group):
             out[i] = i16[b, : int(mel.frames[b]) * hop].copy()

@@ -55,6 +55,54 @@ def check_synthesize_equals_two_calls(eng, g, v, num_symbols, hop, lens=(13, 7, 
     assert np.array_equal(i3, eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9)[2])
 
 
+def check_output_tail_forms(eng, g, v, num_symbols, hop, lens=(13, 7, 21), device_buffers=None):
+    """csrc/voc_out.h (option `voc_out`, default 1): conv_post + tanh + the rows' peaks as ONE dedicated launch and the
+    delivery of the rows (pause before | samples | zeros) as one more, against round 4's ten launches: float rows within
+    f32 round-off (conv_post's fmaf chains vs the padded MFMA tile), int16 within 1 LSB, the zero regions exactly zero — host
+    and device destinations, a ragged batch, with and without the float output, and behind the denoiser."""
+    rng = np.random.default_rng(43)
+    s = ljspeech_audio_settings()
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, num_symbols) for n in lens]
+    for ids in (rows[0], rows):
+        mel = eng.glow_infer(g, ids, 0.667, 1.0, seed=17, audio_settings=s)
+        B = len(mel.frames)
+        got = {}
+        for form in (1, 0):
+            eng.set_option("voc_out", form)
+            try:
+                eng.profile_reset()
+                f, i = eng.hifigan_infer(v, mel, pad_before=3, pad_after=6)
+                names = eng.kernel_counts()
+                assert names["post_conv_kernel"] == form and names["wave_out_kernel"] == form
+                _, ionly = eng.hifigan_infer(v, mel, want_float=False, pad_before=3, pad_after=6)
+                fonly, _ = eng.hifigan_infer(v, mel, want_int16=False)
+                n = mel.max_frames * hop + 16
+                df, di = np.full((B, n), 7.0, np.float32), np.full((B, n), 7, np.int16)
+                if device_buffers is None:
+                    eng.hifigan_infer_raw(v, mel, df.ctypes.data, di.ctypes.data, n, flags=ffi.OUT_DEVICE, pad_before=3, pad_after=6)
+                else:
+                    df, di = device_buffers(eng, v, mel, n, 3, 6)
+                got[form] = (f, i, ionly, fonly, df, di)
+            finally:
+                eng.set_option("voc_out", 1)
+        a, b = got[1], got[0]
+        assert np.abs(a[0] - b[0]).max() <= 2e-6 and np.abs(a[3] - b[3]).max() <= 2e-6 and np.abs(a[4] - b[4]).max() <= 2e-6
+        for k in (1, 2, 5):
+            assert np.abs(a[k].astype(np.int32) - b[k].astype(np.int32)).max() <= 1
+        assert np.array_equal(a[1], a[2])  # with or without the float output
+        for r in range(B):
+            nr = int(mel.frames[r]) * hop
+            for arr in (a[0], a[1], a[4], a[5]):
+                assert np.all(arr[r, :3] == 0) and np.all(arr[r, 3 + nr :] == 0)
+            assert np.array_equal(a[4][r, : 3 + nr], a[0][r, : 3 + nr]) and np.array_equal(a[5][r, : 3 + nr], a[1][r, : 3 + nr])
+            assert np.all(a[3][r, nr:] == 0) and np.array_equal(a[3][r, :nr], a[0][r, 3 : 3 + nr])
+        mel.free()
+
+
+def test_output_tail_forms(emu_engine, tiny):
+    check_output_tail_forms(emu_engine, tiny["g"], tiny["v"], HP.TINY_GLOW.num_symbols, HP.TINY_HIFIGAN.hop)
+
+
 def test_synthesize_equals_two_calls(emu_engine, tiny):
     check_synthesize_equals_two_calls(emu_engine, tiny["g"], tiny["v"], HP.TINY_GLOW.num_symbols, HP.TINY_HIFIGAN.hop)
 

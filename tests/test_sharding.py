@@ -59,6 +59,43 @@ def test_micro_batched_shard_equals_single_calls(emu_engine):
     assert np.abs(direct[0, : one[3].shape[0]].astype(np.int32) - one[3].astype(np.int32)).max() <= 1
 
 
+def test_shard_of_a_multi_speaker_voice(emu_engine):
+    """`speaker_ids` ride with the utterances (indexed like the seeds): the micro-batched shard of a multi-speaker voice equals
+    the single calls with each utterance's own speaker, a missing list is the library's error, a short one a ValueError."""
+    import dataclasses
+
+    import pytest
+
+    from larynx_amd import ffi
+    from larynx_amd import hparams as HP
+    from larynx_amd import sharding, synthetic
+
+    hp = dataclasses.replace(HP.TINY_GLOW, n_speakers=3, gin_channels=20)
+    g = emu_engine.load_glow(hp, synthetic.make_glow_state_dict(hp, seed=9))
+    v = emu_engine.load_hifigan(HP.TINY_HIFIGAN, synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=9))
+    rng = np.random.default_rng(2)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, hp.num_symbols) for n in (8, 13, 6, 10)]
+    spk = [2, 0, 1, 2]
+    try:
+        one = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=70, speaker_ids=spk)
+        many = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=70, batch=3, speaker_ids=spk)
+        other = sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, noise_scale=0.667, seed=70, speaker_ids=[0, 0, 0, 0])
+        for i in range(4):
+            assert one[i].shape == many[i].shape
+            assert np.abs(one[i].astype(np.int32) - many[i].astype(np.int32)).max() <= 1
+            mel = emu_engine.glow_infer(g, rows[i], 0.667, 1.0, seed=70 + i, speaker_ids=spk[i])
+            _, direct = emu_engine.hifigan_infer(v, mel, want_float=False)
+            assert np.array_equal(direct[0, : one[i].shape[0]], one[i])
+        assert any(one[i].shape != other[i].shape or not np.array_equal(one[i], other[i]) for i in (0, 2, 3))  # the speakers matter
+        with pytest.raises(ffi.Mi355ttsError, match="speaker"):
+            sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1)
+        with pytest.raises(ValueError):
+            sharding.synthesize_shard(emu_engine, g, v, rows, 0, 1, speaker_ids=[0, 1])
+    finally:
+        emu_engine.unload(g)
+        emu_engine.unload(v)
+
+
 def _worker(rank, world, port, lib, out_dir):
     sys.path.insert(0, str(REPO))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
