@@ -269,7 +269,11 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  * for the 128-row tile's own threshold move to it when the dispatcher's round-robin deal of their (all resident) workgroups,
  * laid out as a snake, stays balanced (0 = they keep the 64 x 32 k-split tile: same results up to summation order);
  * "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
- * the call's worker; "wn_layer" (0 / 1 / 2, default 0: profiles/r05_wn_layer_ab.txt) — the WaveNet layers of the GlowTTS decoder (glow_tts/layers.py:138-162)
+ * the call's worker; "gate16_wide" (default 512) — gate convs of passes with at least this many 16-row tiles (padded batches,
+ * coalesced passes) run two row tiles per workgroup from one staged input tile (0 = never; same bits); "voc_out" (0/1, default 1)
+ * — conv_post + tanh + the rows' peaks as one dedicated launch and the delivery of the rows (pause | samples | zeros) as one
+ * more (voc_out.h; 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per piece of every row: float rows
+ * equal to f32 round-off, int16 within 1 LSB); "wn_layer" (0 / 1 / 2, default 0: profiles/r05_wn_layer_ab.txt) — the WaveNet layers of the GlowTTS decoder (glow_tts/layers.py:138-162)
  * as ONE column-owner launch each (wn_layer.h: gate conv + gate + res_skip conv on 16-column owners; the throughput form)
  * instead of the gate16 + lin16 launches (the latency form): 0 = never, 2 = always, 1 = when the pass has at least
  * "wn_layer_min_tiles" (default 48) 16-column tiles over its rows — padded batches, coalesced passes — or other calls hold

@@ -57,11 +57,16 @@ struct Gate16Args {
   long long cond_bs;
 };
 
-// K taps, J = 4-channel groups per k-group (Cin <= 32 J)
-template <int K, int J>
+// K taps, J = 4-channel groups per k-group (Cin <= 32 J), RTW = row tiles (of 8 gate channels) per workgroup.
+// RTW = 1 is the batch-1 shape (twice the workgroups of the 32-row tile: see above).  In a WIDE pass — a padded batch, a
+// coalesced pass: BASELINE config 4 has ~1100 decoder columns — the 16-row tile yields ~900 workgroups that each stage the
+// same [Cin x 40] tile for 60 MFMAs per wave (15.9 us per launch at 23 % of the matrix pipes): RTW = 2 stages it once for two
+// row tiles.  A row tile's arithmetic does not depend on RTW (same fragments, same chains, same order of the eight partial
+// sums): same bits.
+template <int K, int J, int RTW = 1>
 __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
   GLOW_PRIO();
-  __shared__ float xs[(32 * J * GATE16_XW > 4096) ? 32 * J * GATE16_XW : 4096];  // [32 J][48]; afterwards the partial tiles [8][2][4][64]
+  __shared__ float xs[(32 * J * GATE16_XW > 4096 * RTW) ? 32 * J * GATE16_XW : 4096 * RTW];  // [32 J][48]; afterwards the partial tiles [RTW][8][2][4][64]
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
   const int b = blockIdx.z;
   const int L = a.len ? a.len[b] * a.len_mul : a.len_const;
@@ -81,15 +86,18 @@ __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
   constexpr int CP = 32 * J;  // staged channel rows
   constexpr int XW = GATE16_XW, XW4 = XW / 4;
   const int PA = (a.pad + 3) & ~3;
+  const int nty = (a.half + 7) / 8;  // row tiles of the conv (the last workgroup row may own fewer than RTW)
 
   // ---- every load whose address is known at entry: the A fragments of this k-group ...
-  float af[J][K];
-  {
-    const float* wp = a.w + ((long long)(ty * 8 + kg) * (J * K)) * 64 + lane;
+  float af[RTW][J][K];
+#pragma unroll
+  for (int r = 0; r < RTW; ++r) {
+    const int t = ty * RTW + r < nty ? ty * RTW + r : nty - 1;
+    const float* wp = a.w + ((long long)(t * 8 + kg) * (J * K)) * 64 + lane;
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int k = 0; k < K; ++k) af[j][k] = wp[(j * K + k) * 64];
+      for (int k = 0; k < K; ++k) af[r][j][k] = wp[(j * K + k) * 64];
   }
   // ... and the activation tile (16 bytes per lane, clamped addresses, zeroed by select)
   constexpr int NF4 = CP * XW4, NE = (NF4 + 511) / 512;
@@ -121,7 +129,9 @@ __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
   GATE_STAMP(1);
 
   // ---- main loop: B fragment lane (n = lane & 15, kq = lane >> 4) = x[4 g + kq][t0 + n + k dil - pad]
-  gate_floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  gate_floatx4 acc0[RTW], acc1[RTW];
+#pragma unroll
+  for (int r = 0; r < RTW; ++r) acc0[r] = acc1[r] = gate_floatx4{0.f, 0.f, 0.f, 0.f};
   {
     const float* bp = xs + (4 * kg + (lane >> 4)) * XW + (lane & 15) + (PA - a.pad);
 #pragma unroll
@@ -129,40 +139,50 @@ __global__ __launch_bounds__(512) void gate16_kernel(const Gate16Args a) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float* p = bp + (32 * j) * XW + k * a.dil;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[16], acc1, 0, 0, 0);
+        const float b0 = p[0], b1 = p[16];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r) {
+          acc0[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j][k], b0, acc0[r], 0, 0, 0);
+          acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j][k], b1, acc1[r], 0, 0, 0);
+        }
       }
     }
   }
   GATE_STAMP(2);
   __syncthreads();
-  // ---- the k-groups' partial tiles: red[kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
-  {
-    float* red = xs + (kg * 2) * 256 + lane;
+  // ---- the k-groups' partial tiles: red[row tile][kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[r * 64] = acc0[r];
-      red[256 + r * 64] = acc1[r];
+  for (int r = 0; r < RTW; ++r) {
+    float* red = xs + r * 4096 + (kg * 2) * 256 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[q * 64] = acc0[r][q];
+      red[256 + q * 64] = acc1[r][q];
     }
   }
   __syncthreads();
   GATE_STAMP(3);
-  if (tid < 256) {
-    const int i = tid >> 5, n = tid & 31;  // gate channel 8 ty + i, column t0 + n
-    const int src = (n >> 4) * 256 + (i & 3) * 64 + (i >> 2) * 16 + (n & 15);
-    float v0 = a.bias[ty * 16 + i], v1 = a.bias[ty * 16 + 8 + i];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      v0 += xs[g * 512 + src];
-      v1 += xs[g * 512 + src + 32];  // row i + 8: two 16-lane groups further
+  for (int r0 = 0; r0 < RTW; r0 += 2) {
+    const int r = r0 + (tid >> 8);  // threads 0-255: row tile r0, 256-511: r0 + 1
+    if (r < RTW && ty * RTW + r < nty) {
+      const int tt = tid & 255, tyr = ty * RTW + r;
+      const int i = tt >> 5, n = tt & 31;  // gate channel 8 tyr + i, column t0 + n
+      const int src = r * 4096 + (n >> 4) * 256 + (i & 3) * 64 + (i >> 2) * 16 + (n & 15);
+      float v0 = a.bias[tyr * 16 + i], v1 = a.bias[tyr * 16 + 8 + i];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        v0 += xs[g * 512 + src];
+        v1 += xs[g * 512 + src + 32];  // row i + 8: two 16-lane groups further
+      }
+      const int c = tyr * 8 + i, t = t0 + n;
+      if (a.cond) {  // x_in + g_l (layers.py:154)
+        const float* cd = a.cond + (long long)b * a.cond_bs + (c < a.half ? c : a.half - 1);
+        v0 += cd[0];
+        v1 += cd[a.half];
+      }
+      if (c < a.half && t < L) a.y[(long long)b * a.y_bs + (long long)c * a.y_ld + t] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
     }
-    const int c = ty * 8 + i, t = t0 + n;
-    if (a.cond) {  // x_in + g_l (layers.py:154)
-      const float* cd = a.cond + (long long)b * a.cond_bs + (c < a.half ? c : a.half - 1);
-      v0 += cd[0];
-      v1 += cd[a.half];
-    }
-    if (c < a.half && t < L) a.y[(long long)b * a.y_bs + (long long)c * a.y_ld + t] = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
   }
   GATE_STAMP(4);
 }
@@ -210,12 +230,16 @@ struct Lin16Args {
 };
 
 // K taps, J = 4-channel groups per k-group (Cin <= 32 J), NBLK = 16-column blocks per workgroup (1 or 2)
-template <int K, int J, int NBLK, bool LN = false>
+// RTW = row tiles per workgroup (1: the batch-1 shape; 4: the 1 x 1 convs of WIDE passes — a padded batch's res_skip conv is
+// ~900 16-row tiles that each stage the same [Cin x 40] tile for 12 MFMAs per wave; a row tile's arithmetic does not depend on
+// RTW: same bits)
+template <int K, int J, int NBLK, bool LN = false, int RTW = 1>
 __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   GLOW_PRIO();
   constexpr int TC = 16 * NBLK;  // columns per workgroup
   constexpr int XW = TC + MI355TTS_G16_HALO;  // staged columns per channel row
-  __shared__ float xs[(32 * J * XW > 2048 * NBLK) ? 32 * J * XW : 2048 * NBLK];  // [32 J][XW]; afterwards the partial tiles [8][NBLK][4][64]
+  __shared__ float xs[(32 * J * XW > 2048 * NBLK * RTW) ? 32 * J * XW : 2048 * NBLK * RTW];  // [32 J][XW]; afterwards the partial tiles [RTW][8][NBLK][4][64]
+  static_assert(RTW == 1 || (TC == 32 && !LN), "several row tiles per workgroup: the 512 threads are one row tile's epilogue");
   __shared__ float lnred[LN ? 8 * 64 : 1];
   static_assert(!LN || XW <= 64, "LayerNorm prologue: one lane per staged column");
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
@@ -237,13 +261,16 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   const int PA = (a.pad + 3) & ~3;
 
   // ---- every load whose address is known at entry
-  float af[J][K];
-  {
-    const float* wp = a.w + ((long long)(ty * 8 + kg) * (J * K)) * 64 + lane;
+  const int nty = (a.rows + 15) / 16;
+  float af[RTW][J][K];
+#pragma unroll
+  for (int r = 0; r < RTW; ++r) {
+    const int t = ty * RTW + r < nty ? ty * RTW + r : nty - 1;
+    const float* wp = a.w + ((long long)(t * 8 + kg) * (J * K)) * 64 + lane;
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int k = 0; k < K; ++k) af[j][k] = wp[(j * K + k) * 64];
+      for (int k = 0; k < K; ++k) af[r][j][k] = wp[(j * K + k) * 64];
   }
   constexpr int NF4 = CP * XW4, NE = (NF4 + 511) / 512;
   const float* xb = a.x + (long long)b * a.x_bs;
@@ -259,15 +286,23 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   // the epilogue's operands too: thread (row i, column n) of the tile
   const int ei = tid / TC, en = tid - ei * TC;
   const bool ethread = tid < 16 * TC;
-  const int erow = ty * 16 + (ethread ? ei : 0), et = t0 + en;
-  const bool eok = ethread && erow < a.rows && et < L;
-  const float ebias = a.bias[ty * 16 + (ethread ? ei : 0)];
-  const bool second = ty * 16 >= a.split;  // uniform per workgroup
-  float eres = 0.f;
-  if (!second) {
-    if (a.res) eres = a.res[(long long)b * a.y_bs + (long long)(eok ? erow : 0) * a.y_ld + (eok ? et : 0)];
-  } else if (a.accum2) {
-    eres = a.y2[(long long)b * a.y2_bs + (long long)(eok ? erow - a.split : 0) * a.y2_ld + (eok ? et : 0)];
+  const int et = t0 + en;
+  int erow[RTW];
+  bool eok[RTW], second[RTW];
+  float ebias[RTW], eres[RTW];
+#pragma unroll
+  for (int r = 0; r < RTW; ++r) {
+    const int tyr = ty * RTW + r < nty ? ty * RTW + r : nty - 1;
+    erow[r] = tyr * 16 + (ethread ? ei : 0);
+    eok[r] = ethread && ty * RTW + r < nty && erow[r] < a.rows && et < L;
+    ebias[r] = a.bias[tyr * 16 + (ethread ? ei : 0)];
+    second[r] = tyr * 16 >= a.split;  // uniform per row tile
+    eres[r] = 0.f;
+    if (!second[r]) {
+      if (a.res) eres[r] = a.res[(long long)b * a.y_bs + (long long)(eok[r] ? erow[r] : 0) * a.y_ld + (eok[r] ? et : 0)];
+    } else if (a.accum2) {
+      eres[r] = a.y2[(long long)b * a.y2_bs + (long long)(eok[r] ? erow[r] - a.split : 0) * a.y2_ld + (eok[r] ? et : 0)];
+    }
   }
   float lg[LN ? 4 * J : 1], lb[LN ? 4 * J : 1];  // LayerNorm gamma / beta of this wave's rows (kg, kg + 8, ...)
   if constexpr (LN) {
@@ -345,9 +380,11 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   }
 
   // ---- main loop: B fragment lane (n = lane & 15, kq = lane >> 4) = x[4 (g + 8 j) + kq][t0 + n + k dil - pad]
-  gate_floatx4 acc[NBLK];
+  gate_floatx4 acc[RTW][NBLK];
 #pragma unroll
-  for (int nb = 0; nb < NBLK; ++nb) acc[nb] = gate_floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < RTW; ++r)
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) acc[r][nb] = gate_floatx4{0.f, 0.f, 0.f, 0.f};
   {
     const float* bp = xs + (4 * kg + (lane >> 4)) * XW + (lane & 15) + (PA - a.pad);
 #pragma unroll
@@ -355,32 +392,41 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float* p = bp + (32 * j) * XW + k * a.dil;
+        float bf[NBLK];
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][k], p[16 * nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBLK; ++nb) bf[nb] = p[16 * nb];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int nb = 0; nb < NBLK; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j][k], bf[nb], acc[r][nb], 0, 0, 0);
       }
     }
   }
   __syncthreads();
-  // ---- the k-groups' partial tiles: red[kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
-  {
-    float* red = xs + (kg * NBLK) * 256 + lane;
+  // ---- the k-groups' partial tiles: red[row tile][kg][column block][reg][lane]; C/D map: row = 4 (lane >> 4) + reg, col = lane & 15
+#pragma unroll
+  for (int r = 0; r < RTW; ++r) {
+    float* red = xs + r * (2048 * NBLK) + (kg * NBLK) * 256 + lane;
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[nb * 256 + r * 64] = acc[nb][r];
+      for (int q = 0; q < 4; ++q) red[nb * 256 + q * 64] = acc[r][nb][q];
   }
   __syncthreads();
   if (ethread) {
     const int src = (en >> 4) * 256 + (ei & 3) * 64 + (ei >> 2) * 16 + (en & 15);
-    float v = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) v += xs[g * (NBLK * 256) + src];
-    v += ebias;
-    v += eres;
-    if (a.relu && !second) v = v > 0.f ? v : 0.f;
-    if (eok) {
-      if (!second) a.y[(long long)b * a.y_bs + (long long)erow * a.y_ld + et] = v;
-      else a.y2[(long long)b * a.y2_bs + (long long)(erow - a.split) * a.y2_ld + et] = v;
+    for (int r = 0; r < RTW; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += xs[r * (2048 * NBLK) + g * (NBLK * 256) + src];
+      v += ebias[r];
+      v += eres[r];
+      if (a.relu && !second[r]) v = v > 0.f ? v : 0.f;
+      if (eok[r]) {
+        if (!second[r]) a.y[(long long)b * a.y_bs + (long long)erow[r] * a.y_ld + et] = v;
+        else a.y2[(long long)b * a.y2_bs + (long long)(erow[r] - a.split) * a.y2_ld + et] = v;
+      }
     }
   }
 }

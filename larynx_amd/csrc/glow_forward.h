@@ -229,6 +229,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   hipStream_t s = w->stream;
   w->o_glow_fuse = ctx->glow_fuse.load();  // one read per call: the launch helpers below use the snapshot
   w->o_gate16 = ctx->gate16.load();
+  w->o_gate16_wide = ctx->gate16_wide.load();
   const int wn_opt = ctx->wn_layer.load();
   const int wn_min_tiles = ctx->wn_layer_min_tiles.load();
   const bool wn_loaded = ctx->active_calls.load(std::memory_order_relaxed) > 1;  // other calls hold workers right now

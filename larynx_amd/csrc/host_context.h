@@ -20,13 +20,13 @@ static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_
 // same launch counts per class, same bits by design), so the device tests assert on these.
 enum KName {
   KN_CONV_MFMA = 0, KN_CONV_M128, KN_CONV_GROUP, KN_RB_CONV, KN_RB_GROUP, KN_RB_GROUP_SNAKE, KN_PAIR, KN_PAIR_GROUP, KN_RB_PAIR,
-  KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_LIN16,
-  KN_LIN16_LN, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_COUNT
+  KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_GATE16_WIDE, KN_LIN16,
+  KN_LIN16_LN, KN_LIN16_WIDE, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_COUNT
 };
 static const char* kname_name[KN_COUNT] = {
     "conv_mfma_kernel", "conv_mfma_kernel.m128", "conv_group_kernel", "rb_conv_kernel", "rb_group_kernel", "rb_group_kernel.snake",
     "resblock_pair_kernel", "pair_group_kernel", "rb_pair_kernel", "rb_pair_group_kernel", "conv_bf16_kernel", "conv_bf16_group_kernel",
-    "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "lin16_kernel", "lin16_kernel.ln",
+    "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "gate16_kernel.wide", "lin16_kernel", "lin16_kernel.ln", "lin16_kernel.wide",
     "wn_layer_kernel", "wn_layer_kernel.gate_only", "glow_tail_kernel", "oproj_ln_kernel", "post_conv_kernel", "wave_out_kernel"};
 // the launch helpers without a context argument (launch_conv_k, launch_group_k) count through this: set by run_plan / run_group
 static thread_local std::atomic<long long>* g_kn = nullptr;
@@ -110,6 +110,7 @@ struct Worker {
   // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
   // a mi355tts_set_option from another thread never changes a call's schedule half way through)
   bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true, o_group_promote = true;
+  int o_gate16_wide = 512;  // wide passes (at least this many 16-row tiles; 0 = never): two row tiles per gate16 workgroup
   bool o_wn_layer = false;  // this call's decoder runs its WaveNet layers as column-owner launches (wn_layer.h)
   // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
   // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
@@ -136,6 +137,7 @@ struct mi355tts_ctx {
   // launches the members of a grouped step one by one (and never forks its MRF chains)
   std::atomic<int> active_calls{0};
   std::atomic<bool> adaptive_schedule{false};
+  std::atomic<int> gate16_wide{512};  // ... with two row tiles per workgroup in passes of at least this many 16-row tiles (0 = never; same bits)
   std::atomic<bool> gate16{true};     // GlowTTS WaveNet gate convs on 16-row tiles (gate16.h) when the launch is small
   // GlowTTS column-owner launches (coltile.h: block tails, conv_o + LayerNorm) AND the whole-tile-in-LDS convs of
   // gate16.h's lin16_kernel (FFN / duration predictor / prenet / 1 x 1 convs, LayerNorm prologues): 0 = the generic tiles
@@ -196,6 +198,7 @@ static void snapshot_options(mi355tts_ctx* ctx, Worker* w) {
   w->o_rb_conv = ctx->rb_conv.load();
   w->o_rb_pair = ctx->rb_pair.load();
   w->o_group_promote = ctx->group_promote.load();
+  w->o_gate16_wide = ctx->gate16_wide.load();
   w->o_wn_layer = false;
 }
 

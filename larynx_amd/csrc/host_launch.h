@@ -765,6 +765,16 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   return 0;
 }
 
+template <int KK, int JJ>
+static void gate16_launch(bool wide, dim3 grid, hipStream_t s, const Gate16Args& g) {
+  if constexpr (JJ == 6) {
+    if (wide) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gate16_kernel<KK, JJ, 2>), grid, dim3(512), 0, s, g);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(gate16_kernel<KK, JJ, 1>), grid, dim3(512), 0, s, g);
+}
 // ---- the WaveNet gate conv on 16-row tiles (gate16.h).  Returns 1 when this conv / launch is not one the kernel takes
 // (the caller then launches the 32-row tile), 0 when launched, < 0 on error.  `a` is the ConvArgs of the same launch.
 static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvArgs& a, int B, int n_max, int cls, hipStream_t s) {
@@ -784,8 +794,11 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   g.y = a.y; g.y_bs = a.y_bs; g.y_ld = a.y_ld;
   g.cond = a.cond; g.cond_bs = a.cond_bs;
   ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B, s);
-  const dim3 grid(gx, gy, B);
-#define GATE16_LAUNCH(KK, JJ) hipLaunchKernelGGL(HIP_KERNEL_NAME(gate16_kernel<KK, JJ>), grid, dim3(512), 0, s, g)
+  // wide passes (padded batches, coalesced passes): two row tiles per workgroup from one staged tile — same bits (gate16.h)
+  const long long wide_min = w->o_gate16_wide;
+  const bool wide = wide_min > 0 && c.g16_J == 6 && (gy % 2) == 0 && (long long)gx * gy * B >= wide_min;  // (the released voices' width)
+  const dim3 grid(gx, wide ? gy / 2 : gy, B);
+#define GATE16_LAUNCH(KK, JJ) gate16_launch<KK, JJ>(wide, grid, s, g)
 #define GATE16_J(KK)                      \
   switch (c.g16_J) {                      \
     case 1: GATE16_LAUNCH(KK, 1); break;  \
@@ -805,7 +818,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   }
 #undef GATE16_J
 #undef GATE16_LAUNCH
-  ctx->kn[KN_GATE16].fetch_add(1, std::memory_order_relaxed);
+  ctx->kn[wide ? KN_GATE16_WIDE : KN_GATE16].fetch_add(1, std::memory_order_relaxed);
   return 0;
 }
 
@@ -839,7 +852,11 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   // measured 3 % faster alone and 1.2 % slower with 8 calls in flight than the 64-row tile (profiles/NOTES.md)
   // (explicit batches only: a batch-1 call always takes this form, and so does a coalesced pass, whose rows must equal
   // their batch-1 results whatever their lengths)
-  if (c.K == 1 && B > 1 && !solo_tiles && (long long)gx * gy * B > 512) return 1;
+  // Round 5: such passes take FOUR row tiles per workgroup from one staged tile (lin16_kernel<..., RTW = 4>: same bits as the
+  // 16-row launch, a quarter of the staging) — option "gate16_wide" (the pass size from which; 0 = round 4's rule)
+  const bool wide = c.K == 1 && c.l16_J == 6 && !ln && nblk == 2 && (gy % 4) == 0 && w->o_gate16_wide > 0 &&
+                    (long long)gx * gy * B >= w->o_gate16_wide;
+  if (!wide && c.K == 1 && B > 1 && !solo_tiles && (long long)gx * gy * B > 512) return 1;
   Lin16Args g;
   std::memset(&g, 0, sizeof(g));
   g.x = a.x; g.x_bs = a.x_bs; g.x_ld = a.x_ld;
@@ -854,9 +871,10 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
     g.ln_gamma = ln->gamma; g.ln_beta = ln->beta; g.ln_eps = 1e-4f; g.ln_relu = ln->relu; g.ln_out = ln->out;
   }
   ProfScope ps(ctx, w, cls, 2.0 * (double)c.Cout * c.Cin * c.K * (double)n_max * B);
-  const dim3 grid(gx, gy, B);
+  const dim3 grid(gx, wide ? gy / 4 : gy, B);
   hipStream_t s = w->stream;
-  if (ln && c.K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2, true>), grid, dim3(512), 0, s, g);
+  if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2, false, 4>), grid, dim3(512), 0, s, g);
+  else if (ln && c.K == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2, true>), grid, dim3(512), 0, s, g);
   else if (ln && c.K == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2, true>), grid, dim3(512), 0, s, g);
   else if (ln && c.K == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 8, 2, true>), grid, dim3(512), 0, s, g);
   else if (c.K == 3 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<3, 6, 2>), grid, dim3(512), 0, s, g);
@@ -865,7 +883,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 1 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2>), grid, dim3(512), 0, s, g);
   else return 1;
-  ctx->kn[ln ? KN_LIN16_LN : KN_LIN16].fetch_add(1, std::memory_order_relaxed);
+  ctx->kn[wide ? KN_LIN16_WIDE : ln ? KN_LIN16_LN : KN_LIN16].fetch_add(1, std::memory_order_relaxed);
   return 0;
 }
 

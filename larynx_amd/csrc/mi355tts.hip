@@ -1275,6 +1275,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->glow_priority = value;
     return 0;
   }
+  if (std::strcmp(name, "gate16_wide") == 0) {
+    ctx->gate16_wide = value < 0 ? 0 : value;
+    return 0;
+  }
   if (std::strcmp(name, "voc_out") == 0) {
     ctx->voc_out = value != 0;
     return 0;

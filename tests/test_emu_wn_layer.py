@@ -176,3 +176,30 @@ def test_automatic_rule(emu_engine):
     finally:
         emu_engine.set_option("wn_layer", 0)
         emu_engine.unload(g)
+
+
+def test_wide_gate_tile_computes_the_same_bits(emu_engine):
+    """`gate16_kernel<K, J, 2>` / `lin16_kernel<1, 6, 2, false, 4>` (option `gate16_wide` = the pass size from which they are
+    used): two / four row tiles per workgroup from one staged input tile — a row tile's arithmetic does not depend on it, so
+    the bits are the 16-row launch's; a ragged batch and a multi-speaker voice (the `cond` offsets)."""
+    hp = _hp(n_blocks_dec=1, n_block_layers=2, n_speakers=3, gin_channels=8)
+    sd = synthetic.make_glow_state_dict(hp, seed=151)
+    g = emu_engine.load_glow(hp, sd)
+    rng = np.random.default_rng(152)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, hp.num_symbols) for n in (11, 4, 8)]
+    try:
+        got = {}
+        for wide in (1, 0):
+            emu_engine.set_option("gate16_wide", wide)
+            try:
+                got[wide] = _counts(emu_engine, lambda: _mels(emu_engine, g, rows, True, speaker_ids=[1, 2, 0]))
+            finally:
+                emu_engine.set_option("gate16_wide", 512)
+        assert got[1][1]["gate16_kernel.wide"] == 2 and got[1][1]["gate16_kernel"] == 0
+        assert got[0][1]["gate16_kernel.wide"] == 0 and got[0][1]["gate16_kernel"] == 2
+        # ... and the 1 x 1 convs with whole groups of four row tiles (res_skip: 2H rows, qkv: 3H) four row tiles per workgroup
+        assert got[1][1]["lin16_kernel.wide"] >= 2 and got[0][1]["lin16_kernel.wide"] == 0
+        for a, b in zip(got[1][0], got[0][0]):
+            assert np.array_equal(a, b)
+    finally:
+        emu_engine.unload(g)
