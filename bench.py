@@ -43,7 +43,7 @@ sys.path.insert(0, str(REPO))
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, f32 MFMA = f32 vector peak
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 SAMPLE_RATE = 22050
-ROUND = "r04"
+ROUND = "r05"
 
 
 def algorithmic_flop(P: int, F: float, quality: str = "high") -> float:

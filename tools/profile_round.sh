@@ -4,7 +4,7 @@
 #   WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes), MFMA-busy PMC pass.
 # Usage: tools/profile_round.sh r01
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
