@@ -289,6 +289,14 @@ int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
  * profiles/NOTES.md) — for loads where GlowTTS dominates.  Counters since the context was created: passes run with the
  * option on, rows they carried. */
 int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows);
+/* One-off check of the dispatcher rule the batch-1 ResBlock schedule relies on (grouped launches whose workgroups are all
+ * resident go out in a "snake" order that assumes workgroup i lands on CU i mod #CUs; the promotion of a step to the 128-row
+ * tile relies on that order): the grouped launch of a 256-channel ResBlock step in the plain and in the snake order, timed on
+ * this device.  Runs by itself on the first load of a vocoder with a >= 256-channel stage; where the snake is not at least as
+ * fast (2 % margin) both are switched off for the context (options "group_snake", "group_promote").  state: 1 = kept, 2 =
+ * switched off, 3 = skipped (MI355TTS_NO_SELFCHECK, unsuitable CU count); times in microseconds per launch.  No reference
+ * counterpart. */
+int mi355tts_dispatch_selfcheck(mi355tts_ctx* ctx, int* state, float* plain_us, float* snake_us);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
 /* Launches per kernel NAME since the last mi355tts_profile_reset, {"rb_group_kernel": n, ...}; counted whether profiling is

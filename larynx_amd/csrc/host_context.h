@@ -110,6 +110,7 @@ struct Worker {
   // the context's kernel-selection options as THIS call saw them at its start (glow_run / hifigan_run snapshot them once, so
   // a mi355tts_set_option from another thread never changes a call's schedule half way through)
   bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true, o_group_promote = true;
+  bool o_snake = true;  // grouped launches whose workgroups are all resident go out in the snake order (group_snake_order)
   int o_gate16_wide = 512;  // wide passes (at least this many 16-row tiles; 0 = never): two row tiles per gate16 workgroup
   bool o_wn_layer = false;  // this call's decoder runs its WaveNet layers as column-owner launches (wn_layer.h)
   // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
@@ -153,6 +154,13 @@ struct mi355tts_ctx {
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
   std::atomic<bool> group_promote{true};  // batch-1 ResBlock steps move to the 128-row tile when the snake deal is balanced (promote_group_plans)
+  // Grouped launches whose workgroups are all resident at once are laid out as a snake over the dispatcher's rounds
+  // (group_snake_order).  That order — and the promotion rule that relies on it — encodes an OBSERVED dispatcher rule (workgroup i
+  // -> CU i mod #CUs); mi355tts_dispatch_selfcheck times it against the plain order on this device (first 'high'-class vocoder
+  // load) and turns both off where the snake does not win (a partitioned GPU, another CU count, a firmware that deals differently).
+  std::atomic<bool> group_snake{true};
+  std::atomic<int> selfcheck_state{0};  // 0 = not run, 1 = snake kept, 2 = snake and promotion disabled, 3 = skipped / failed
+  float selfcheck_plain_us = 0.f, selfcheck_snake_us = 0.f;
   std::atomic<bool> rb_pair{true};    // fused ResBlock steps (64 / 32 channels) on the 4-wave tile without a k-split (rb_pair.h)
   // mi355tts_synthesize: GlowTTS on a high-priority stream of the call's worker (see Worker::gstream).  The hardware queues
   // run one kernel at a time each and the runtime maps all bulk streams onto 4 of them: a call's chain of ~140 small
@@ -198,6 +206,7 @@ static void snapshot_options(mi355tts_ctx* ctx, Worker* w) {
   w->o_rb_conv = ctx->rb_conv.load();
   w->o_rb_pair = ctx->rb_pair.load();
   w->o_group_promote = ctx->group_promote.load();
+  w->o_snake = ctx->group_snake.load();
   w->o_gate16_wide = ctx->gate16_wide.load();
   w->o_wn_layer = false;
 }

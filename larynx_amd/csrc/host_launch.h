@@ -543,7 +543,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     for (int i = 0; i < 3; ++i) rb_ok = rb_ok && rb_member_ok(g.c[i], i == 0 ? 11 : i == 1 ? 7 : 3);
     if (rb_ok) {
       static const bool no_snake = [] { const char* e = std::getenv("MI355TTS_NO_SNAKE"); return e && std::atoi(e) != 0; }();
-      if (grid.z == 1 && !no_snake) group_snake_order(g, ncu, 4 * ncu);  // four of these workgroups fit a CU (32 KB, <= 128 VGPRs)
+      if (grid.z == 1 && !no_snake && w->o_snake) group_snake_order(g, ncu, 4 * ncu);  // four of these workgroups fit a CU (32 KB, <= 128 VGPRs)
       kn_add(g.nseg ? KN_RB_GROUP_SNAKE : KN_RB_GROUP);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), grid, dim3(256), 0, s, g);
       return 0;

@@ -401,6 +401,7 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
   return 0;
 }
 
+static int dispatch_selfcheck_run(mi355tts_ctx* ctx);
 extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_hparams* hp, const float* blob,
                                      int64_t numel, int on_device, int* model_out) {
   if (!ctx || !blob || !model_out) return fail(MI355TTS_ERR_INVALID, "null argument");
@@ -582,6 +583,8 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
           fix16(rc.c2);
         }
       }
+  // the first vocoder with a 256-channel stage: check the dispatcher rule its batch-1 schedule relies on (once per context)
+  if ((C0 >> 1) >= 256 && h.resblock_type == 1) dispatch_selfcheck_run(ctx);  // (a failed check leaves the defaults)
   std::lock_guard<std::mutex> lk(ctx->mu);
   const int id = ctx->next_id++;
   ctx->hifi[id] = std::move(hm);
@@ -1225,6 +1228,117 @@ extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout
   return rc;
 }
 
+// One-off check of the dispatcher rule behind group_snake_order / promote_group_plans (host_launch.h) on THIS device: the
+// grouped launch of a 256-channel ResBlock step at the standard utterance's length (3 x 156 tiles of the 128-row tile: all
+// resident at once), eight launches in the plain longest-first order against eight in the snake order, interleaved.  Where the
+// snake is not at least as fast (2 % margin) the order and the promotion that relies on it are switched off for the context.
+// Runs once per context, on the first load of a vocoder with a >= 256-channel stage (or on request); ~15 ms.
+static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
+  int expected = 0;
+  if (!ctx->selfcheck_state.compare_exchange_strong(expected, 3)) return 0;  // someone ran (or is running) it
+  {
+    const char* e = std::getenv("MI355TTS_NO_SELFCHECK");
+    hipDeviceProp_t prop;
+    const bool emu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && std::strncmp(prop.gcnArchName, "hipemu", 6) == 0;
+    if ((e && std::atoi(e) != 0) || emu) return 0;  // (the CPU emulator build of the tests: nothing to measure)
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int C = 256, L = 78 * 64;
+  const int Ks[3] = {11, 7, 3};
+  ArenaBuilder ab;
+  DevConv cv[3];
+  uint32_t st = 2463534242u;
+  auto rnd = [&]() {
+    st = st * 1664525u + 1013904223u;
+    return ((st >> 8) * (1.0f / 16777216.0f)) * 2.0f - 1.0f;
+  };
+  for (int m = 0; m < 3; ++m) {
+    std::vector<float> wh((size_t)C * C * Ks[m]), bh(C, 0.f);
+    const float sc = 1.0f / std::sqrt((float)C * Ks[m]);
+    for (auto& v : wh) v = rnd() * sc;
+    cv[m] = add_conv(ab, wh.data(), bh.data(), C, C, Ks[m], ROWS_PLAIN);
+  }
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
+  Carver cvr;
+  const size_t o_w = cvr.take(ab.host.size() * sizeof(float));
+  const size_t o_x = cvr.take(sizeof(float) * (size_t)C * L);
+  size_t o_y[3];
+  for (int m = 0; m < 3; ++m) o_y[m] = cvr.take(sizeof(float) * (size_t)C * L);
+  CHECK(reserve(w, cvr.pos));
+  char* base = w->arena;
+  float* dw = (float*)(base + o_w);
+  float* dx = (float*)(base + o_x);
+  hipStream_t s = w->stream;
+  HIPCHECK(hipMemcpyAsync(dw, ab.host.data(), ab.host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)C * L, s));
+  ConvPlan plans[3];
+  ConvPlan* pp[3] = {&plans[0], &plans[1], &plans[2]};
+  for (int m = 0; m < 3; ++m) {
+    fix(cv[m], dw);
+    ConvArgs a = base_args(dx, (long long)C * L, L, nullptr, 1, (float*)(base + o_y[m]), (long long)C * L, L, nullptr, 1, 1, (Ks[m] - 1) / 2);
+    a.in_const = a.out_const = L;
+    a.in_slope = 0.1f;
+    CHECK(plan_conv(cv[m], a, EPI_LINEAR, 1, L, KC_RESBLOCK, 1024, L, &plans[m], 0));
+  }
+  const bool prof = ctx->profiling.load();
+  ctx->profiling = false;
+  w->o_group_promote = true;
+  w->o_rb_conv = true;
+  promote_group_plans(ctx, w, pp, 3);
+  int rc = 0;
+  float us[2] = {0.f, 0.f};
+  if (plans[0].shape != TILE_M128) {
+    rc = 1;  // the promotion rule itself declined this geometry on this device (CU count): nothing to check
+  } else {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "hipEventCreate");
+    for (int warm = 0; warm < 2 && !rc; ++warm)
+      for (int order = 0; order < 2 && !rc; ++order) {
+        w->o_snake = order == 1;
+        if (run_group(ctx, w, plans, 3, s) != 0) rc = 1;
+      }
+    for (int rep = 0; rep < 4 && !rc; ++rep)
+      for (int order = 0; order < 2 && !rc; ++order) {
+        w->o_snake = order == 1;
+        hipEventRecord(e0, s);
+        for (int i = 0; i < 2 && !rc; ++i)
+          if (run_group(ctx, w, plans, 3, s) != 0) rc = 1;
+        hipEventRecord(e1, s);
+        float ms = 0.f;
+        if (mi355_sync(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = 1;
+        us[order] += 1e3f * ms / 8.0f;
+      }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+  }
+  ctx->profiling = prof;
+  for (auto& k : ctx->kn) k.store(0, std::memory_order_relaxed);  // (the check's launches are not the caller's)
+  if (rc != 0) return rc < 0 ? rc : 0;  // state stays 3: skipped
+  ctx->selfcheck_plain_us = us[0];
+  ctx->selfcheck_snake_us = us[1];
+  if (us[1] > 1.02f * us[0]) {
+    ctx->group_snake = false;
+    ctx->group_promote = false;
+    ctx->selfcheck_state = 2;
+  } else {
+    ctx->selfcheck_state = 1;
+  }
+  return 0;
+}
+// state: 0 = not run, 1 = the snake order is kept, 2 = the snake order and the promotion rule were switched off on this device,
+// 3 = skipped (MI355TTS_NO_SELFCHECK, the promotion rule declines the geometry on this CU count, emulator); the two times are
+// microseconds per grouped launch (0 when skipped)
+extern "C" int mi355tts_dispatch_selfcheck(mi355tts_ctx* ctx, int* state, float* plain_us, float* snake_us) {
+  if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
+  CHECK(dispatch_selfcheck_run(ctx));
+  if (state) *state = ctx->selfcheck_state.load();
+  if (plain_us) *plain_us = ctx->selfcheck_plain_us;
+  if (snake_us) *snake_us = ctx->selfcheck_snake_us;
+  return 0;
+}
+
 // ------------------------------------------------------------------ measurement
 extern "C" int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
@@ -1261,6 +1375,10 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
   }
   if (std::strcmp(name, "rb_conv") == 0) {
     ctx->rb_conv = value != 0;
+    return 0;
+  }
+  if (std::strcmp(name, "group_snake") == 0) {
+    ctx->group_snake = value != 0;
     return 0;
   }
   if (std::strcmp(name, "group_promote") == 0) {

@@ -429,6 +429,16 @@ def test_vocoder_launch_counts_on_the_device(gpu_engine, quality, resblock, narr
         assert names[k] == n, (k, names)
 
 
+def test_dispatch_order_selfcheck_on_the_device(gpu_engine):
+    """`mi355tts_dispatch_selfcheck`: the dispatcher rule behind the snake order of fully resident grouped launches (and the
+    promotion of the 256-channel stage that relies on it) is MEASURED on the device the library runs on — on an MI355X the snake
+    order must win (profiles/r04_rb_diag_snake_order.txt: 121 us against 133 for the plain order), and the options stay on."""
+    models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)  # the first 'high'-class load runs the check by itself
+    r = gpu_engine.dispatch_selfcheck()
+    assert r["state"] == "snake order kept", r
+    assert 50.0 < r["snake_us"] <= 1.02 * r["plain_us"] < 400.0, r
+
+
 def test_promoted_stage_really_runs_on_the_device(gpu_engine):
     """The 256-channel stage of 'high' at batch 1 takes the 128-row tile in snake order (`promote_group_plans`; the golden parity
     tests above run through it).  Option "group_promote" = 0 sends the same step to the 64 x 32 k-split tile — another summation
