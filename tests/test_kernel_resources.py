@@ -111,11 +111,26 @@ def test_glow_small_launch_kernels(resources):
     spills; the P <= 256 instantiation at 77 KB of LDS instead of the 141 KB of the P <= 768 one; the shipped voices'
     dk = 96 variant well under 128 registers)."""
     gate = {n: r for n, r in resources.items() if "gate16_kernel" in n}
-    assert len(gate) == 12, sorted(gate)
+    assert len(gate) == 14, sorted(gate)  # 2 tap counts x 6 widths, + the wide-pass form (two row tiles per workgroup) of H = 192
     for n, r in gate.items():
         assert r["scratch"] == 0 and r["vgprs"] <= 128, (n, r)
-    h192 = [r for n, r in gate.items() if "ILi5ELi6E" in n]
+    h192 = [r for n, r in gate.items() if "ILi5ELi6ELi1E" in n]
     assert len(h192) == 1 and h192[0]["lds"] <= 31 * 1024
+    wide = [r for n, r in gate.items() if "ILi5ELi6ELi2E" in n]
+    assert len(wide) == 1 and wide[0]["lds"] <= 32 * 1024 and wide[0]["vgprs"] <= 96
+
+
+def test_round5_kernels(resources):
+    """wn_layer_kernel (wn_layer.h): four waves per SIMD by registers (<= 128, no scratch) and under 32 KB of LDS — the hole one
+    finishing ResBlock workgroup leaves; post_conv_kernel (voc_out.h): no scratch, three workgroups per CU."""
+    wn = {n: r for n, r in resources.items() if "wn_layer_kernel" in n}
+    assert len(wn) == 4, sorted(wn)  # k = 5 / 3, with / without the res_skip phase
+    for n, r in wn.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 128 and r["lds"] <= 32 * 1024 and r["occupancy"] >= 4, (n, r)
+    post = {n: r for n, r in resources.items() if "post_conv_kernel" in n}
+    assert len(post) == 3, sorted(post)
+    for n, r in post.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 168 and r["lds"] <= 24 * 1024, (n, r)
     att = {n: r for n, r in resources.items() if "attention_mfma_kernel" in n}
     assert len(att) == 16, sorted(att)
     for n, r in att.items():
