@@ -252,6 +252,13 @@ static int plan_conv(const DevConv& c, ConvArgs a, int epi, int B, int n_max, in
     MB = 1;
     ytiles = rows32;
   }
+  {
+    // A 64-row upsampler (the last stage of 'high': 64 -> 32 channels x 2 phases, two taps) is bound by its input planes, not
+    // by its matrix work (81 MB against 1.3 GFLOP): the 128-column shape is ONE m-tile high, so two workgroups stage every
+    // input tile; the 64-row x 64-column shape stages it once.  MI355TTS_UPS64=0: the shape rule above (A/B runs).
+    static const bool ups64 = [] { const char* e = std::getenv("MI355TTS_UPS64"); return !e || std::atoi(e) != 0; }();
+    if (ups64 && !pinned && epi == EPI_UPSAMPLE && c.MB == 2 && rows32 == 2 && shape == TILE_W128 && tiles(64) >= 256) shape = TILE_SMALL;
+  }
   if (shape == TILE_W128 && MB == 2) {
     MB = 1;
     ytiles = rows32;

@@ -34,24 +34,27 @@ namespace mi355tts {
 #endif
 
 // ring buffer stride: whole sweeps of the 256 threads (a thread past the tile's last float4 stores into padding)
-template <int HALO, int NB = 2>
-constexpr int rb_buf_floats() { return ((16 * (32 * NB + HALO) / 4 + 255) / 256) * 256 * 4; }
-template <int HALO, int NB = 2>
-constexpr int rb_lds_floats() { return 4 * rb_buf_floats<HALO, NB>(); }
+template <int HALO, int NB = 2, int CI_C = 16>
+constexpr int rb_buf_floats() { return ((CI_C * (32 * NB + HALO) / 4 + 255) / 256) * 256 * 4; }
+template <int HALO, int NB = 2, int CI_C = 16>
+constexpr int rb_lds_floats() { return 4 * rb_buf_floats<HALO, NB, CI_C>(); }
 
 // One workgroup (4 waves = 4 row groups of 32 rows) = rows [128 tile_y, +128) x columns [64 tile_x, +64) of batch row b.
 // EPI_LINEAR: ConvArgs x (no x2 / x3), bias, res, y; alpha = 1, no accumulate / activation / row split (the host checks).
 // EPI_UPSAMPLE: the polyphase ConvTranspose1d of conv_tile (K = 2 taps, rows = C_out * u virtual rows scattered to
 // q u + r - pad), optionally with MRF = the consumer-side MRF average: input = ((x + x2) + x3) / in_div, summed when the
 // tile is written to LDS — the three planes' loads go out together a chunk earlier, nothing waits for them.
-template <int K, int HALO, int EPI = EPI_LINEAR, bool MRF = false, int NB = 2>
+// CI_C = channels per staged chunk (16 everywhere).  32 was measured for the two-tap upsamplers, whose 16-channel chunk is only
+// 32 MFMAs per wave between two chunk seams: 48 KB of LDS and 141 VGPRs instead of 32 KB / 101 for -2 us per utterance
+// (profiles/NOTES.md, round 5) — not instantiated.  The MFMA sequence does not depend on it: same bits.
+template <int K, int HALO, int EPI = EPI_LINEAR, bool MRF = false, int NB = 2, int CI_C = 16>
 __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, const int tile_y, const int b, float* __restrict__ xs) {
   static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "rb_tile: linear and upsample epilogues");
-  constexpr int CI_C = 16, NT = 256, T_T = 32 * NB;  // NB column blocks of 32 per wave: 64-column tiles, or 32 (NB = 1) where a
+  constexpr int NT = 256, T_T = 32 * NB;  // NB column blocks of 32 per wave: 64-column tiles, or 32 (NB = 1) where a
   // launch would otherwise have too few workgroups (the 256-channel stage at batch 1)
   constexpr int XW = T_T + HALO, XW4 = XW / 4, OCTS = CI_C / 8, S = OCTS * K;
   constexpr int NF4 = CI_C * XW4, NE = (NF4 + NT - 1) / NT;
-  constexpr int BUF = rb_buf_floats<HALO, NB>();  // floats per ring buffer (>= CI_C * XW)
+  constexpr int BUF = rb_buf_floats<HALO, NB, CI_C>();  // floats per ring buffer (>= CI_C * XW)
   static_assert(BUF == NE * NT * 4, "ring stride = whole thread sweeps");
   static_assert(XW % 4 == 0 && S >= NE + 2, "bad tile parameters");
 
@@ -403,9 +406,9 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
 }
 
 // one conv per launch on the same tile (the polyphase upsamplers): grid = (time tiles, 128-row tiles, batch rows)
-template <int K, int HALO, int EPI, bool MRF>
-__global__ __launch_bounds__(256, 4) void rb_conv_kernel(const ConvArgs a) {
-  __shared__ float xs[rb_lds_floats<HALO>()];
+template <int K, int HALO, int EPI, bool MRF, int CI_C = 16>
+__global__ __launch_bounds__(256, CI_C == 16 ? 4 : 3) void rb_conv_kernel(const ConvArgs a) {
+  __shared__ float xs[rb_lds_floats<HALO, 2, CI_C>()];
   int tile_x, tile_y;
   int gx = gridDim.x;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256, 4) void rb_conv_kernel(const ConvArgs a) {
     if (lin >= gx * (int)gridDim.y) return;
   }
   xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
-  rb_tile<K, HALO, EPI, MRF>(a, tile_x, tile_y, blockIdx.z, xs);
+  rb_tile<K, HALO, EPI, MRF, 2, CI_C>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // halo of the staged tile per tap count: (K - 1) d for d <= 5, plus the 4-alignment slack of the tile origin
