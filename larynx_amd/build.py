@@ -32,17 +32,39 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def resources_hash() -> str:
+    """The key tests/test_kernel_resources.py files the compiler's resource remarks under."""
+    h = hashlib.sha1()
+    for f in sorted(CSRC.glob("*")) + [REPO / "include" / "mi355tts.h"]:
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     digest = source_hash()
     if not force and OUT.is_file() and STAMP.is_file() and STAMP.read_text().strip() == digest:
         return OUT
+    # -Rpass-analysis=kernel-resource-usage: the compiler's per-kernel VGPR / scratch / LDS / occupancy remarks, kept under
+    # build/ (git-ignored) keyed by the source state — tests/test_kernel_resources.py reads them instead of compiling the
+    # device code a second time (two to three minutes)
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-        str(CSRC / "mi355tts.hip"), "-o", str(OUT),
+        "-Rpass-analysis=kernel-resource-usage", str(CSRC / "mi355tts.hip"), "-o", str(OUT),
     ]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=str(REPO))
+    proc = subprocess.run(cmd, cwd=str(REPO), stderr=subprocess.PIPE, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stderr[-8000:])
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    try:
+        cache_dir = REPO / "build"
+        cache_dir.mkdir(exist_ok=True)
+        for old in cache_dir.glob("kernel_resources_*.txt"):
+            old.unlink()
+        (cache_dir / f"kernel_resources_{resources_hash()}.txt").write_text(proc.stderr)
+    except OSError:
+        pass
     STAMP.write_text(digest)
     return OUT
 

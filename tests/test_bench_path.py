@@ -23,7 +23,7 @@ def _run(emu_library, gpus, utterances=7):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gpus,utterances", [(1, 7), (2, 7), (8, 19)])
+@pytest.mark.parametrize("gpus,utterances", [(2, 7), (8, 19)])
 def test_bench_line_at_world_size(emu_library_path, gpus, utterances):
     out = _run(emu_library_path, gpus, utterances)
     assert out["n_gpus"] == gpus and out["steps"] == 3 and out["warmup"] == 1
