@@ -255,6 +255,7 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
     for (int nb = 0; nb < NB; ++nb) {
       const int q = t0 + nb * 32 + col;
       if (q >= n_len) continue;
+      if ((RB_ABL & 32) && q != 0) continue;  // (probe builds: the scatter stores ablated)
       if ((a.up & 3) == 0 && (a.up_pad & 3) == 0 && (a.y_ld & 3) == 0) {
         // registers 4g .. 4g+3 of a lane = 4 consecutive phases of ONE output channel = 4 consecutive, 16-byte aligned samples
 #pragma unroll
