@@ -1284,6 +1284,8 @@ static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
   }
   const bool prof = ctx->profiling.load();
   ctx->profiling = false;
+  long long kn_before[KN_COUNT];
+  for (int i = 0; i < KN_COUNT; ++i) kn_before[i] = ctx->kn[i].load(std::memory_order_relaxed);
   w->o_group_promote = true;
   w->o_rb_conv = true;
   promote_group_plans(ctx, w, pp, 3);
@@ -1314,7 +1316,7 @@ static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
     if (e1) hipEventDestroy(e1);
   }
   ctx->profiling = prof;
-  for (auto& k : ctx->kn) k.store(0, std::memory_order_relaxed);  // (the check's launches are not the caller's)
+  for (int i = 0; i < KN_COUNT; ++i) ctx->kn[i].store(kn_before[i], std::memory_order_relaxed);  // (the check's launches are not the caller's)
   if (rc != 0) return rc < 0 ? rc : 0;  // state stays 3: skipped
   ctx->selfcheck_plain_us = us[0];
   ctx->selfcheck_snake_us = us[1];
