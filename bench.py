@@ -185,6 +185,80 @@ def config4_rows(num_symbols: int):
     return [synthetic.synthetic_phoneme_ids(rng, n, num_symbols) for n in CONFIG4_P], 0.5, "seeded synthetic ids"
 
 
+def micro_batch_leg(eng, g, v, ghp, vhp, args, dev, barrier, timed, world, red_dev, use_dist, audio, rank):
+    """The headline's utterances as MICRO-BATCHES: 8 standard utterances per fused call (a padded batch; every row with its own
+    noise stream), 2 calls in flight — what a serving front-end that batches gets (sharding.synthesize_shard(batch = 8)).  Same
+    models, same arithmetic; rows equal their batch-1 results up to f32 summation order (a padded batch picks other tiles)."""
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+    import torch.distributed as dist
+
+    from larynx_amd import ffi
+    from larynx_amd import synthetic
+
+    MB, threads = 8, 2
+    K = 2 * max(4, args.steps // 4)  # calls per region: whole rounds of the two callers
+    rng = np.random.default_rng(777 + rank)
+    ids_host = np.stack([synthetic.synthetic_phoneme_ids(rng, args.ids, ghp.num_symbols) for _ in range(MB * (K + 1))])
+    ids_dev = torch.from_numpy(ids_host).to(dev)
+    lens = np.full(MB, args.ids, np.int32)
+    hop = vhp.hop
+    max_frames = args.ids * 12
+    max_samples = max_frames * hop
+    wav_f32 = [torch.empty(MB * max_samples, dtype=torch.float32, device=dev) for _ in range(threads)]
+    wav_i16 = [torch.empty(MB * max_samples, dtype=torch.int16, device=dev) for _ in range(threads)]
+    flags = ffi.IN_DEVICE | ffi.OUT_DEVICE
+    eng.reserve(threads + 1, g, v, max_batch=MB, max_ids=max(args.ids, 200), max_frames=max_frames)
+    frames_seen = []
+
+    def call(i, slot=0):
+        fr = eng.synthesize_raw(g, v, ids_dev[i * MB].data_ptr(), lens, args.ids, 0.667, args.length_scale, wav_f32[slot].data_ptr(),
+                                wav_i16[slot].data_ptr(), max_samples, seed=9000 + MB * i, audio_settings=audio, flags=flags)
+        return fr
+
+    pool = ThreadPoolExecutor(threads)
+
+    def run(n):
+        q = queue.SimpleQueue()
+        for i in range(n):
+            q.put(i)
+
+        def work(slot):
+            while True:
+                try:
+                    i = q.get_nowait()
+                except queue.Empty:
+                    return
+                call(i, slot)
+
+        list(pool.map(work, range(threads)))
+
+    frames_seen = call(0)
+    run(threads * 2)
+    reps = max(5, min(20, int(np.ceil(1.0 / max(1e-4, min(timed(lambda: run(K), 1)))))))
+    t = timed(lambda: run(K), reps)
+    pool.shutdown()
+    st = torch.tensor([float(np.median(t)), min(t), max(t)], dtype=torch.float64, device=red_dev)
+    if use_dist:
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    dt, dt_min, dt_max = (float(x) for x in st)
+    return {
+        "what": f"the headline's standard utterances as padded micro-batches: {MB} utterances per fused call, {threads} calls in flight "
+                "(a front-end that batches: sharding.synthesize_shard(batch = 8)); same models and arithmetic, every row its own noise stream",
+        "batch": MB,
+        "calls_in_flight_per_gpu": threads,
+        "steps": K,
+        "repeats": reps,
+        "utterances_per_sec": world * K * MB / dt,
+        "ms_per_utterance": 1e3 * dt / (K * MB),
+        "ms_per_utterance_min": 1e3 * dt_min / (K * MB),
+        "ms_per_utterance_max": 1e3 * dt_max / (K * MB),
+        "frames_per_utterance": float(np.mean(frames_seen)),
+    }
+
+
 def config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_dist, audio):
     """BASELINE config 4 on this rank; returns the `config4` object (timings MAX-reduced over ranks)."""
     import torch
@@ -345,6 +419,7 @@ def main():
     ap.add_argument("--config3-utterances", type=int, default=256)
     ap.add_argument("--no-config4", action="store_true", help="skip BASELINE config 4 (thorsten + 'medium', one padded batch of 8)")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-micro-batch", action="store_true", help="skip the micro-batched leg (8 utterances per call, 2 calls in flight)")
     ap.add_argument("--config5-sentences", type=int, default=210)
     ap.add_argument("--config5-threads", type=int, default=3,
                     help="host threads per GPU in the streaming config (the reference's raw-stream default is 2: fewer workers "
@@ -849,6 +924,11 @@ def main():
     if not args.no_config4 and not args.tiny and on_gpu:
         c4 = config4_leg(eng, args, dev, barrier, timed, pool, conc, world, red_dev, use_dist, s)
 
+    # ---- the same utterances as micro-batches of 8 (2 calls in flight): what batching buys on top of the batch-1 headline
+    mb = None
+    if B == 1 and on_gpu and not args.tiny and not args.no_micro_batch and args.precision == "f32":
+        mb = micro_batch_leg(eng, g, v, ghp, vhp, args, dev, barrier, timed, world, red_dev, use_dist, s, rank)
+
     if rank == 0:
         audio_s = total_frames * hop / SAMPLE_RATE  # audio produced by all ranks in one K-step region
         utt_s = world * K * B / dt_flight
@@ -1027,6 +1107,8 @@ def main():
             out["config3"] = c3
         if c4 is not None:
             out["config4"] = c4
+        if mb is not None:
+            out["micro_batched"] = mb
         if c5 is not None:
             out["config5"] = c5
         if not args.no_cpu_baseline and world == 1 and on_gpu and not args.tiny:
