@@ -2,13 +2,16 @@
 // (glow_tts/layers.py:138-162 — x_in = in_layers[i](x) [+ g_l]; acts = tanh(x_in[:H]) * sigmoid(x_in[H:])
 // (glow_tts/utils.py:31-38); res_skip = res_skip_layers[i](acts); x = (x + res_skip[:H]) * mask; output += res_skip[H:]).
 //
-// Why a second form.  gate16.h / lin16_kernel shape this layer for a LONE batch-1 call: 240 + 120 workgroups of 512 threads
-// that each stage a [H x 40] tile, run 30-60 MFMAs per wave and meet in LDS — 8 + 5 us on an idle chip, at 3-10 % of the
-// matrix pipes.  Next to other calls the price of a launch is not its latency but the CU residency it takes from the
-// vocoder's ResBlock workgroups (profiles/NOTES.md, round 4: 0.38-0.45 ms per utterance for 3.8 % of the FLOPs), and in a
-// padded batch (BASELINE config 4) the same launches are most of the call.  Here a workgroup OWNS 16 time columns with all
-// their channels and runs the layer's 442 k MAC per column out of LDS: 20 workgroups x ~25 us for a 312-column decoder
-// instead of 360 x 8, the activations of a layer never leave the CU, and gate conv + gate + res_skip are one launch.
+// STATUS: measured and NOT in the default path (option "wn_layer" = 0).  The form was built on the reading that, next to other
+// calls, a GlowTTS launch costs the CU residency it takes from the vocoder's ResBlock workgroups, not its latency (VERDICT
+// r04): gate16.h / lin16_kernel run this layer as 240 + 120 workgroups of 512 threads that each stage a [H x 40] tile, run
+// 30-60 MFMAs per wave and meet in LDS (8 + 5 us on an idle chip at 3-10 % of the matrix pipes); here a workgroup OWNS 16 time
+// columns with all their channels and runs the layer's 442 k MAC per column out of LDS — 20 workgroups for a 312-column
+// decoder, the activations of a layer never leave the CU, gate conv + gate + res_skip are one launch.  On the device
+// (profiles/r05_wn_layer_ab.txt): 40.6 us per layer alone (1.77 MB of fragments through one CU with 30 KB in flight), 72.5 us
+// under load; 243 utterances/s against the chain's 281 with eight calls in flight, BASELINE config 4 2.48 ms per call
+// against 2.00 (a padded batch of 8 is 70 column owners on 256 CUs).  Under load many short workgroups that request all
+// their operands at entry beat few long ones; the kernel stays as the tested, bit-identical record of that answer.
 //
 // Shape of a workgroup: 4 waves (one per SIMD), <= 128 VGPRs, 31 KB of LDS — the hole ONE finishing ResBlock workgroup
 // (rb_conv.h: 4 waves, 32 KB) leaves on a loaded CU, so a launch needs no drained CU to start.
