@@ -1055,7 +1055,7 @@ def main():
                     "unit": "TFLOP/s",
                     "frac": 3.0 * half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
                     "note": "executed bf16 MFMA work (3 x the algorithmic f32 FLOPs) / dense bf16 peak; the f32-equivalent rate above is what a "
-                            "caller sees; PMC of these kernels: profiles/r04_bf16x3_pmc_by_kernel.csv",
+                            "caller sees; PMC of these kernels: profiles/r05_bf16x3_pmc_by_kernel.csv",
                     "launches": half[2]["launches"],
                     "avg_launch_us": 1e3 * half[2]["ms"] / max(1, half[2]["launches"]),
                     # raw event durations here; the same figure without the empty-event-pair cost (see roofline.timing)
