@@ -121,6 +121,30 @@ def cpu_baseline(ids: np.ndarray, length_scale: float, max_seconds: float = 45.0
     }
 
 
+def by_kernel_table(prof_kernels: dict, glow_top: int = 5) -> dict:
+    """`roofline.by_kernel`: launches and average RAW event microseconds per kernel name / sub-key (output rows of a conv launch,
+    channels of a fused ResBlock step) of the profiled single-stream pass — every kernel of the ResBlock and upsampler classes,
+    the vocoder's pre / post convs and the `glow_top` GlowTTS kernels with the largest total time.  A driver record on an unknown
+    box can be compared with the builder's kernel by kernel (round 5's table: profiles/r05_by_kernel.json)."""
+    out = {}
+
+    def rows(cls):
+        return {k: {"launches": int(v["launches"]), "avg_us": 1e3 * v["ms"] / max(1, v["launches"]), "total_ms": v["ms"]}
+                for k, v in prof_kernels.get(cls, {}).items()}
+
+    for cls in ("conv_mfma.hifigan_resblock", "conv_mfma.hifigan_upsample", "conv_mfma.hifigan_pre_post", "mrf_small.hifigan_narrow_stage"):
+        r = rows(cls)
+        if r:
+            out[cls] = r
+    glow = {}
+    for cls in ("conv_mfma.glow_encoder", "conv_mfma.glow_decoder", "elementwise"):
+        for k, v in rows(cls).items():
+            glow[f"{cls}:{k}"] = v
+    top = sorted(glow.items(), key=lambda kv: -kv[1]["total_ms"])[:glow_top]
+    out["glow_top"] = dict(top)
+    return out
+
+
 def pin_rank_to_gpu_numa(local: int) -> dict:
     """Keep this rank's host threads (the ThreadPoolExecutor feeding its GPU, torch's intra-op pool) on the NUMA node its GPU
     hangs off: /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<N>/cpulist -> sched_setaffinity.
@@ -420,6 +444,8 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip BASELINE config 4 (thorsten + 'medium', one padded batch of 8)")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--no-micro-batch", action="store_true", help="skip the micro-batched leg (8 utterances per call, 2 calls in flight)")
+    ap.add_argument("--call-coalesce-lanes", type=int, default=2,
+                    help="lanes of the call_coalesce A/B leg when the library's default is 0 (option call_coalesce; csrc/host_join.h)")
     ap.add_argument("--config5-sentences", type=int, default=210)
     ap.add_argument("--config5-threads", type=int, default=3,
                     help="host threads per GPU in the streaming config (the reference's raw-stream default is 2: fewer workers "
@@ -562,8 +588,8 @@ def main():
     dn_ok = 88 * hop > 1024  # the denoiser's 1024-point STFT needs a real vocoder hop (not the emulator's tiny one)
     eng.reserve(conc + 1, g, v, max_batch=B, max_ids=max(args.ids, 200), max_frames=max(max_frames, 2400), denoiser=dn_ok)
     if B == 1 and conc > 1:
-        # concurrent batch-1 calls share GlowTTS passes (csrc/host_join.h): any worker may lead a pass of up to `conc` rows
-        eng.reserve(conc + 1, g, 0, max_batch=conc, max_ids=max(args.ids, 200), max_frames=max_frames)
+        # concurrent batch-1 calls may ride fused padded calls (csrc/host_join.h): any worker may lead a pass of up to `conc` rows
+        eng.reserve(conc + 1, g, v, max_batch=conc, max_ids=max(args.ids, 200), max_frames=max_frames)
 
     def step(i, slot=0, denoiser=0.0):
         """One utterance (one batch of B) through the fused call; returns its frame count."""
@@ -634,6 +660,7 @@ def main():
     barrier()
     dt_prof = time.perf_counter() - t0
     prof = eng.profile()
+    prof_kernels = eng.profile_kernels()
     eng.set_profiling(False)
     eng.set_option("serial_branches", 1 if args.serial_branches else 0)
     step(W)
@@ -643,17 +670,19 @@ def main():
     repeats = args.repeats if args.repeats > 0 else int(min(40, max(5, np.ceil(2.0 / est))))
     t_single = timed(lambda: run_steps(W, n_utts, threads=1), repeats)
     t_flight = timed(lambda: run_steps(W, n_utts), repeats) if conc > 1 else t_single
-    # the same region with the callers sharing GlowTTS passes (option glow_coalesce = 1, off by default), reported next to
-    # the headline
+    # the same region with the other setting of option "call_coalesce" (csrc/host_join.h: concurrent batch-1 callers become the
+    # rows of fused padded calls), reported next to the headline — which runs the library's DEFAULT
     t_flight_nc = t_flight
     cs0 = cs1 = (0, 0)
+    cc_default = eng.get_call_coalesce_default()
+    cc_other = 0 if cc_default else args.call_coalesce_lanes
     if conc > 1 and B == 1:
-        eng.set_option("glow_coalesce", 1)
+        eng.set_option("call_coalesce", cc_other)
         run_steps(0, max(W, conc))
         cs0 = eng.coalesce_stats()
         t_flight_nc = timed(lambda: run_steps(W, n_utts), max(3, repeats // 3))
         cs1 = eng.coalesce_stats()
-        eng.set_option("glow_coalesce", 0)
+        eng.set_option("call_coalesce", cc_default)
         run_steps(0, max(W, conc))
     t_dn = timed(lambda: run_steps(W, n_utts, denoiser=0.005), max(3, repeats // 3)) if dn_ok else [float("nan")]
     # ---- steady state: the SAME calls in regions ten times as long.  A K-step region starts on an idle GPU (every caller begins
@@ -1015,11 +1044,13 @@ def main():
                 "ms_per_step": 1e3 * dt_voc / K,
                 "utterances_per_sec": world * K * B / dt_voc,
             },
-            "glow_coalescing": None if not (conc > 1 and B == 1) else {
-                "what": "option glow_coalesce = 1 (default 0): concurrent batch-1 calls share GlowTTS passes — the callers waiting when a "
-                        "pass starts become the rows of one padded batch (csrc/host_join.h); bit-identical results "
-                        "(tests/test_emu_coalesce.py, tests/test_gpu_parity.py::test_coalesced_calls_equal_their_solitary_results). "
-                        "NOT the headline: the same timed region with the option on",
+            "call_coalescing": None if not (conc > 1 and B == 1) else {
+                "what": f"option call_coalesce = {cc_other} (the library default, which the headline runs, is {cc_default}): concurrent batch-1 "
+                        "mi355tts_synthesize callers become the rows of fused padded calls — acoustic pass and vocoder — at most that many "
+                        "in flight (csrc/host_join.h); rows equal their solitary calls to f32 round-off (tests/test_emu_coalesce.py, "
+                        "tests/test_gpu_parity.py::test_coalesced_calls_equal_their_solitary_results).  NOT the headline: the same timed "
+                        "region with the option at its other setting",
+                "call_coalesce": cc_other,
                 "rows_per_pass": (cs1[1] - cs0[1]) / max(1, cs1[0] - cs0[0]),
                 "utterances_per_sec": world * K * B / dt_flight_nc,
                 "ms_per_step": 1e3 * dt_flight_nc / K,
@@ -1103,6 +1134,7 @@ def main():
             },
             "profile_ms_per_step": {k_: v_["ms"] / K for k_, v_ in prof.items()},
         }
+        out["roofline"]["by_kernel"] = by_kernel_table(prof_kernels)
         if c3 is not None:
             out["config3"] = c3
         if c4 is not None:

@@ -255,50 +255,65 @@ int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout, int K, in
  * call's own stream and accumulated per kernel class.  `mi355tts_profile_json`
  * writes {"class": {"launches": n, "ms": t, "flop": f}, ...}. */
 int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
-/* options: "serial_branches" (0/1) — run the three MRF ResBlock chains of a
- * HiFi-GAN stage one after another on one stream instead of concurrently on
- * three (used when timing single kernels); "mrf_group" (0/1, default 1) — the
- * same-geometry launches of the three chains go out as one grouped launch; "adaptive_schedule"
- * (0/1, default 0) — while other calls are in flight, launch the members of a group one by one
- * (and, with "mrf_group" = 0, do not fork the chains onto side streams); "gate16", "glow_fuse", "mrf_small" (0/1, default 1)
- * — the small-launch kernels of gate16.h / coltile.h / mrf_small.h (0 = the generic tiles; same results up to summation
- * order); "rb_conv" (0/1, default 1) — the grouped 128-row ResBlock launches on the continuous-stream tile of rb_conv.h
- * (0 = the chunked tile of conv_mfma.h; same bits); "rb_pair" (0/1, default 1) — the fused ResBlock steps of the 64- / 32-channel
- * stages on the 4-wave tile without a k-split (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h: same results up to
- * summation order); "group_promote" (0/1, default 1) — at batch 1 the same-geometry ResBlock convs of a step that are too short
- * for the 128-row tile's own threshold move to it when the dispatcher's round-robin deal of their (all resident) workgroups,
- * laid out as a snake, stays balanced (0 = they keep the 64 x 32 k-split tile: same results up to summation order);
- * "glow_priority" (0/1, default 0) — mi355tts_synthesize runs its acoustic pass on a high-priority stream of
- * the call's worker; "gate16_wide" (default 512) — gate convs of passes with at least this many 16-row tiles (padded batches,
- * coalesced passes) run two row tiles per workgroup from one staged input tile (0 = never; same bits); "voc_out" (0/1, default 1)
- * — conv_post + tanh + the rows' peaks as one dedicated launch and the delivery of the rows (pause | samples | zeros) as one
- * more (voc_out.h; 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per piece of every row: float rows
- * equal to f32 round-off, int16 within 1 LSB); "wn_layer" (0 / 1 / 2, default 0: profiles/r05_wn_layer_ab.txt) — the WaveNet layers of the GlowTTS decoder (glow_tts/layers.py:138-162)
- * as ONE column-owner launch each (wn_layer.h: gate conv + gate + res_skip conv on 16-column owners; the throughput form)
- * instead of the gate16 + lin16 launches (the latency form): 0 = never, 2 = always, 1 = when the pass has at least
- * "wn_layer_min_tiles" (default 48) 16-column tiles over its rows — padded batches, coalesced passes — or other calls hold
- * workers of this context when the call starts; both forms compute the SAME BITS (same fragments, same chains, same order
- * of the partial sums), so the choice may follow the load; "glow_coalesce" (below).  The schedule options give the same bits
- * under every setting. */
+/* Options, by what they may change in a RESULT.
+ *
+ * (1) Schedule options that compute THE SAME BITS under every setting (the same tiles run the same arithmetic; only which
+ * launch, stream or workgroup order carries them changes):
+ *   "serial_branches" (0/1, default 0) — the three MRF ResBlock chains of a HiFi-GAN stage one after another, one conv per
+ *     launch (per-kernel timing); "mrf_group" (0/1, default 1) — the same-geometry launches of the three chains as one grouped
+ *     launch; "adaptive_schedule" (0/1, default 0) — while other calls are in flight, launch the members of a group one by one;
+ *   "rb_conv" (0/1, default 1) — the grouped 128-row ResBlock launches on the continuous-stream tile of rb_conv.h (0 = the
+ *     chunked tile of conv_mfma.h);
+ *   "group_snake" (0/1, default 1) — the workgroup ORDER of fully resident grouped launches (a snake over the dispatcher's
+ *     rounds).  The one option the library may change by itself: mi355tts_dispatch_selfcheck switches it off on a device where
+ *     the order does not win;
+ *   "gate16_wide" (default 512) — gate convs / 1 x 1 convs of passes with at least this many 16-row tiles (padded batches) take
+ *     two / four row tiles per workgroup from one staged input tile (0 = never).
+ * (2) Tile options: another tile = another f32 SUMMATION ORDER; results equal to f32 round-off, never changed by the library
+ * itself (a timing never picks a tile):
+ *   "gate16", "glow_fuse", "mrf_small" (0/1, default 1) — the small-launch kernels of gate16.h / coltile.h / mrf_small.h
+ *     (0 = the generic tiles);
+ *   "rb_pair" (0/1, default 1) — the fused ResBlock steps of the 64- / 32-channel stages on the 4-wave tile without a k-split
+ *     (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h);
+ *   "group_promote" (0/1, default 1) — at batch 1 the same-geometry ResBlock convs of a step that are too short for the 128-row
+ *     tile's own threshold move to it when the round-robin deal of their (all resident) workgroups stays balanced: decided from
+ *     the device's CU count and the launch geometry alone (0 = they keep the 64 x 32 k-split tile);
+ *   "voc_out" (0/1, default 1) — conv_post + tanh + the rows' peaks as one dedicated launch and the delivery of the rows (pause |
+ *     samples | zeros) as one more (voc_out.h; 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per
+ *     piece of every row: float rows equal to f32 round-off, int16 within 1 LSB).
+ * (0) "sync_mode" (0-3, default 3 or MI355TTS_SYNC_MODE; process-wide) — how a caller thread waits for its stream: 0 =
+ * hipStreamSynchronize (spins a core), 1 = a blocking event, 2 = hipStreamQuery + 20 us sleeps, 3 = 60 us of polling, then
+ * query + 20 us sleeps with the calling thread's timer slack lowered to 1 us FOR THE DURATION OF THE WAIT (prctl
+ * PR_SET_TIMERSLACK on the caller's own thread, restored before the call returns; skipped where prctl is denied).
+ * (3) "call_coalesce" / "call_coalesce_window_us" (below): with it on, WHICH tiles compute a batch-1 call depends on the calls
+ * that happened to share its pass — results equal to f32 round-off across loads, not bit-reproducible. */
 int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int value);
-/* Option "glow_coalesce" (0/1, default 0): concurrent batch-1 mi355tts_synthesize calls (the reference's per-sentence
- * thread pool, larynx/__init__.py:146-157, 187-190) share GlowTTS passes — the callers waiting when a pass starts become
- * the rows of ONE padded batch; each row keeps the noise stream of its own seed and is computed by the launches of its own
- * batch-1 call, so results are the same bits with the option on or off, whoever shared the pass.  Off by default: with the
- * 'high' vocoder the shared passes buy nothing (the waiting they introduce costs what the saved launches gain; measured in
- * profiles/NOTES.md) — for loads where GlowTTS dominates.  Counters since the context was created: passes run with the
- * option on, rows they carried. */
+/* Option "call_coalesce" (lanes; 0 = off; the built-in default: mi355tts_call_coalesce_default): concurrent batch-1
+ * mi355tts_synthesize calls (the reference's per-sentence thread pool, larynx/__init__.py:146-157, 187-190) become the rows of
+ * fused padded calls — acoustic pass AND vocoder — with at most `lanes` such passes in flight: the callers waiting when a lane
+ * frees ride one pass, each row with its own seed's noise stream, its own pause padding and its own output buffers.  A lone
+ * caller never waits (its pass is its solitary call, same bits); a caller that finds a lane free while other passes are in
+ * flight gathers followers for at most "call_coalesce_window_us" (default 300).  Calls with explicit noise, speaker ids,
+ * B > 1 or more than 768 ids always run alone.  A row of a padded batch is computed by other tiles than its solitary call:
+ * equal to f32 round-off (frames identical, int16 within 1 LSB), not bit-identical.  Counters since the context was created:
+ * fused passes run, rows they carried. */
+int mi355tts_call_coalesce_default(void);
 int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows);
 /* One-off check of the dispatcher rule the batch-1 ResBlock schedule relies on (grouped launches whose workgroups are all
  * resident go out in a "snake" order that assumes workgroup i lands on CU i mod #CUs; the promotion of a step to the 128-row
  * tile relies on that order): the grouped launch of a 256-channel ResBlock step in the plain and in the snake order, timed on
  * this device.  Runs by itself on the first load of a vocoder with a >= 256-channel stage; where the snake is not at least as
- * fast (2 % margin) both are switched off for the context (options "group_snake", "group_promote").  state: 1 = kept, 2 =
- * switched off, 3 = skipped (MI355TTS_NO_SELFCHECK, unsuitable CU count); times in microseconds per launch.  No reference
- * counterpart. */
+ * fast (2 % margin) the ORDER option "group_snake" is switched off for the context — results are the same bits either way; the
+ * promotion rule ("group_promote": a tile choice) is never touched by a timing.  state: 1 = kept, 2 = switched off, 3 = skipped
+ * (MI355TTS_NO_SELFCHECK, unsuitable CU count), 4 = running on another thread; times in microseconds per launch.  No
+ * reference counterpart. */
 int mi355tts_dispatch_selfcheck(mi355tts_ctx* ctx, int* state, float* plain_us, float* snake_us);
 int mi355tts_profile_reset(mi355tts_ctx* ctx);
 int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap);
+/* The same sums per kernel NAME and launch sub-key (the output rows of a conv launch / the channels of a fused ResBlock step):
+ * {"class": {"rb_group_kernel.snake/256": {"launches": n, "ms": t, "flop": f}, ...}, ...}; kernels without a counted name are
+ * filed under "-".  No reference counterpart (bench.py's `roofline.by_kernel`). */
+int mi355tts_profile_kernels_json(mi355tts_ctx* ctx, char* buf, int cap);
 /* Launches per kernel NAME since the last mi355tts_profile_reset, {"rb_group_kernel": n, ...}; counted whether profiling is
  * on or not.  The class counters cannot tell a kernel from the fallback that would silently take its place (same launch count,
  * same bits by design): the device tests assert on these.  No reference counterpart (measurement only). */

@@ -240,6 +240,11 @@ __global__ __launch_bounds__(512) void lin16_kernel(const Lin16Args a) {
   constexpr int XW = TC + MI355TTS_G16_HALO;  // staged columns per channel row
   __shared__ float xs[(32 * J * XW > 2048 * NBLK * RTW) ? 32 * J * XW : 2048 * NBLK * RTW];  // [32 J][XW]; afterwards the partial tiles [RTW][8][NBLK][4][64]
   static_assert(RTW == 1 || (TC == 32 && !LN), "several row tiles per workgroup: the 512 threads are one row tile's epilogue");
+  // two workgroups per CU (160 KB of LDS): every form stays under 80 KB, and the RTW = 4 form — whose reduction scratch, not its
+  // staged tile, sets the size: exactly 64 KB — under that; a wider HALO / NBLK / RTW must not pass either silently
+  // (tests/test_kernel_resources.py bounds the compiled figures too)
+  static_assert(sizeof(float) * ((32 * J * XW > 2048 * NBLK * RTW) ? 32 * J * XW : 2048 * NBLK * RTW) <= (RTW > 1 ? 64 : 80) * 1024,
+                "lin16 tile: more LDS than two workgroups per CU allow");
   __shared__ float lnred[LN ? 8 * 64 : 1];
   static_assert(!LN || XW <= 64, "LayerNorm prologue: one lane per staged column");
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;

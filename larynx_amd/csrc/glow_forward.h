@@ -32,7 +32,7 @@ static int run_oproj_ln(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const
   a.w = A + L.o16.w_off; a.b = A + L.o16.b_off; a.gamma = A + L.g1; a.beta = A + L.b1;
   a.H = H; a.eps = 1e-4f;
   ProfScope ps(ctx, w, KC_GLOW_ENC_CONV, 2.0 * (double)H * H * (double)Pmax * B);
-  ctx->kn[KN_OPROJ_LN].fetch_add(1, std::memory_order_relaxed);
+  kn_hit(ctx, KN_OPROJ_LN);
   hipLaunchKernelGGL(oproj_ln_kernel, dim3((Pmax + COL_T - 1) / COL_T, B), dim3(512), 0, w->stream, a);
   return 0;
 }
@@ -60,7 +60,7 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
   a.H = H; a.half = half;
   const double mac = (double)H * H + 2.0 * half * H + (next ? (double)H * half : 0.0);
   ProfScope ps(ctx, w, KC_GLOW_DEC_CONV, 2.0 * mac * (double)F2max * B);
-  ctx->kn[KN_GLOW_TAIL].fetch_add(1, std::memory_order_relaxed);
+  kn_hit(ctx, KN_GLOW_TAIL);
   hipLaunchKernelGGL(glow_tail_kernel, dim3((F2max + COL_T - 1) / COL_T, B), dim3(512), 0, w->stream, a);
   return 0;
 }
@@ -193,7 +193,7 @@ static GlowEncLayout glow_enc_layout(const mi355tts_glow_hparams& h, int B, int 
   return L;
 }
 struct GlowDecLayout {
-  size_t o_z, o_h, o_h2, o_ac, o_sk, o_nz, total;
+  size_t o_z, o_h, o_ac, o_sk, o_nz, total;
 };
 static GlowDecLayout glow_dec_layout(const mi355tts_glow_hparams& h, size_t enc_bytes, int B, int Fmax, size_t host_noise_floats) {
   GlowDecLayout L;
@@ -203,7 +203,6 @@ static GlowDecLayout glow_dec_layout(const mi355tts_glow_hparams& h, size_t enc_
   dv.pos = enc_bytes;
   L.o_z = dv.take(sizeof(float) * (size_t)B * C * F2);
   L.o_h = dv.take(sizeof(float) * (size_t)B * H * F2);
-  L.o_h2 = dv.take(sizeof(float) * (size_t)B * H * F2);  // wn_layer_kernel writes x + res to the OTHER plane (a neighbour reads the halo)
   L.o_ac = dv.take(sizeof(float) * (size_t)B * H * F2);
   L.o_sk = dv.take(sizeof(float) * (size_t)B * H * F2);
   L.o_nz = dv.take(sizeof(float) * host_noise_floats);
@@ -230,9 +229,6 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   w->o_glow_fuse = ctx->glow_fuse.load();  // one read per call: the launch helpers below use the snapshot
   w->o_gate16 = ctx->gate16.load();
   w->o_gate16_wide = ctx->gate16_wide.load();
-  const int wn_opt = ctx->wn_layer.load();
-  const int wn_min_tiles = ctx->wn_layer_min_tiles.load();
-  const bool wn_loaded = ctx->active_calls.load(std::memory_order_relaxed) > 1;  // other calls hold workers right now
   const float* A = gm->arena;
   const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int k = h.kernel_size, nh = h.n_heads;
@@ -338,6 +334,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     }
     {
       ProfScope ps(ctx, w, KC_SMALL, 0);
+      kn_hit(ctx, KN_ATTENTION);
       const dim3 ag((Pmax + 31) / 32, nh, B);
       const int dkh = H / nh;
       static const bool att_big = [] { const char* e = std::getenv("MI355TTS_ATT_BIG_LDS"); return e && std::atoi(e) != 0; }();  // (A/B runs)
@@ -508,7 +505,6 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   }
   float* z = (float*)(base + o_z);
   float* hbuf = (float*)(base + o_h);
-  float* hbuf2 = (float*)(base + dl.o_h2);
   float* acts = (float*)(base + o_ac);
   float* skip = (float*)(base + o_sk);
   const float* d_noise = noise;
@@ -534,17 +530,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     for (int b = 0; b < B; ++b) w->pinned[b] = mel->frames[b] / nsq;
     HIPCHECK(hipMemcpyAsync(d_f2, w->pinned, sizeof(int) * B, hipMemcpyHostToDevice, s));
   }
-  {
-    // The form of the WaveNet layers (same bits either way): column-owner launches (wn_layer.h) when the pass is wide or the
-    // GPU is shared with other calls — then a launch costs the others its CU residency, not its latency —, the 16-row tiles
-    // of gate16.h for a lone short call.  Decided once per call.
-    static const bool wn_off = [] { const char* e = std::getenv("MI355TTS_NO_WN_LAYER"); return e && std::atoi(e) != 0; }();
-    long long tiles = 0;
-    for (int b = 0; b < B; ++b) tiles += (mel->frames[b] / nsq + WN_T - 1) / WN_T;
-    w->o_wn_layer = !wn_off && wn_opt != 0 && w->o_gate16 && glow_fuse_on(w) && (wn_opt >= 2 || tiles >= wn_min_tiles || wn_loaded);
-  }
-  float* hcur = hbuf;   // the WaveNet's hidden state; wn_layer_kernel ping-pongs it between the two planes
-  float* halt = hbuf2;
+  float* const hcur = hbuf;  // the WaveNet's hidden state
   bool start_done = false;  // the previous block's tail launch already ran this block's start conv
   for (int blk = h.n_blocks_dec - 1; blk >= 0; --blk) {  // models.py:195-206, reversed flows
     const GlowBlock& Bk = gm->blocks[blk];
@@ -567,18 +553,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
         a.in_len = a.out_len = nullptr;
         a.in_const = a.out_const = dec_host_len;
       }
-      int wn = 1;  // the whole layer in one launch (the last layer: its gate conv; its res_skip is the tail launch's first step)
-      if (w->o_wn_layer) {
-        wn = run_wn_layer(ctx, w, Bk.in[j], last ? nullptr : &Bk.rs[j], A, hcur, halt, acts, skip, j > 0, bsD, F2, d_f2, dec_host_len, dil,
-                          a.pad, a.cond, a.cond_bs, H, B, F2max);
-        if (wn < 0) return wn;
-      }
-      if (wn == 0 && !last) {
-        std::swap(hcur, halt);
-        dil *= h.dilation_rate;
-        continue;
-      }
-      if (wn != 0) {
+      {
         const int g16 = run_gate16(ctx, w, Bk.in[j], a, B, F2max, KC_GLOW_DEC_CONV, s);
         if (g16 < 0) return g16;
         if (g16 == 1) CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));

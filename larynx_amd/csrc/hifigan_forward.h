@@ -52,6 +52,12 @@ static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
 
 // One vocoder call's outputs: per row [pad_before zeros][frames[b]*hop samples][zeros up to wav_ld]
 // (the pads are the SSML pauses `_sentence_task` adds with np.pad, larynx/__init__.py:277-283).
+struct VocRow {  // one row's destinations when the rows of a call belong to different callers (host_join.h)
+  float* wav_f32 = nullptr;
+  int16_t* wav_i16 = nullptr;
+  int64_t wav_ld = 0;
+  int pad_before = 0, pad_after = 0;
+};
 struct VocCall {
   float denoiser_strength = 0.f;
   float* wav_f32 = nullptr;
@@ -59,6 +65,8 @@ struct VocCall {
   int64_t wav_ld = 0;
   uint32_t flags = 0;
   int pad_before = 0, pad_after = 0;
+  // optional, [B] (B <= VOC_MAX_ROWS): per-row destinations, strides and pauses; the five fields above are then unused
+  const VocRow* rows = nullptr;
 };
 
 // pins the model (see find_glow)
@@ -74,9 +82,19 @@ static int find_hifi(mi355tts_ctx* ctx, int vocoder, std::shared_ptr<HifiModel>*
 static int hifigan_precheck(mi355tts_ctx* ctx, HifiModel* hm, int vocoder, const int32_t* frames, int B, int M, int Fmax,
                             const VocCall& c) {
   if (M != hm->hp.num_mels) return fail(MI355TTS_ERR_INVALID, "mel has %d channels, vocoder expects %d", M, hm->hp.num_mels);
-  if (c.pad_before < 0 || c.pad_after < 0) return fail(MI355TTS_ERR_INVALID, "negative pause padding");
-  const long long need = (long long)Fmax * hm->hop + c.pad_before + c.pad_after;
-  if (Fmax >= 0 && c.wav_ld < need) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)c.wav_ld, need);
+  if (c.rows) {  // per-row destinations: every row against its own frame count
+    if (B > VOC_MAX_ROWS) return fail(MI355TTS_ERR_INVALID, "internal: %d rows with per-row outputs", B);
+    for (int b = 0; b < B; ++b) {
+      const VocRow& r = c.rows[b];
+      if (r.pad_before < 0 || r.pad_after < 0) return fail(MI355TTS_ERR_INVALID, "negative pause padding");
+      const long long need = (long long)(frames ? frames[b] : 0) * hm->hop + r.pad_before + r.pad_after;
+      if (frames && r.wav_ld < need) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)r.wav_ld, need);
+    }
+  } else {
+    if (c.pad_before < 0 || c.pad_after < 0) return fail(MI355TTS_ERR_INVALID, "negative pause padding");
+    const long long need = (long long)Fmax * hm->hop + c.pad_before + c.pad_after;
+    if (Fmax >= 0 && c.wav_ld < need) return fail(MI355TTS_ERR_TOO_SMALL, "wav_ld %lld < %lld samples", (long long)c.wav_ld, need);
+  }
   if (c.denoiser_strength > 0.f && Fmax != 0) {
     // the reference's STFT needs more than one 1024-sample frame per utterance
     // (larynx/audio.py:232-249 raises on shorter input)
@@ -137,6 +155,22 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   const bool out_dev = (call.flags & MI355TTS_OUT_DEVICE) != 0;
   const int pad0 = call.pad_before;
   hipStream_t s = w->stream;
+  const VocRow* const prow = call.rows;
+  if (prow && B > VOC_MAX_ROWS) return fail(MI355TTS_ERR_INVALID, "internal: %d rows with per-row outputs", B);
+  if (F == 0 && prow) {
+    for (int b = 0; b < B; ++b) {
+      const VocRow& r = prow[b];
+      if (out_dev) {
+        if (r.wav_f32) HIPCHECK(hipMemsetAsync(r.wav_f32, 0, sizeof(float) * (size_t)r.wav_ld, s));
+        if (r.wav_i16) HIPCHECK(hipMemsetAsync(r.wav_i16, 0, sizeof(int16_t) * (size_t)r.wav_ld, s));
+      } else {
+        if (r.wav_f32) std::memset(r.wav_f32, 0, sizeof(float) * (size_t)r.wav_ld);
+        if (r.wav_i16) std::memset(r.wav_i16, 0, sizeof(int16_t) * (size_t)r.wav_ld);
+      }
+    }
+    if (out_dev) HIPCHECK(mi355_sync(s));
+    return 0;
+  }
   if (F == 0) {
     if (out_dev) {
       if (wav_f32) HIPCHECK(hipMemsetAsync(wav_f32, 0, sizeof(float) * (size_t)B * wav_ld, s));
@@ -214,7 +248,17 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   const int rb_tiles = rb_env > 0 ? rb_env : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
   const int prec = hm->precision.load();
-  const int pads = call.pad_before + call.pad_after;
+  int pads = call.pad_before + call.pad_after;
+  bool any_f32 = wav_f32 != nullptr, any_i16 = wav_i16 != nullptr;
+  if (prow) {
+    pads = 0;
+    any_f32 = any_i16 = false;
+    for (int b = 0; b < B; ++b) {
+      pads = std::max(pads, prow[b].pad_before + prow[b].pad_after);
+      any_f32 = any_f32 || prow[b].wav_f32;
+      any_i16 = any_i16 || prow[b].wav_i16;
+    }
+  }
   const HifiLayout lay = hifi_layout(h, hop, B, F, denoise, split_out, pads);
   const size_t Nld = lay.Nld;
   const int nbuf = lay.nbuf, Tmax = lay.Tmax;
@@ -436,6 +480,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   // more (voc_out.h); 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per piece of every row.
   static const bool voc_out_off = [] { const char* e = std::getenv("MI355TTS_NO_VOC_OUT"); return e && std::atoi(e) != 0; }();
   const bool vo = !voc_out_off && ctx->voc_out.load() && hm->post_C == ch && hm->post.K == 7 && ldin % 4 == 0;
+  if (prow && !vo) return fail(MI355TTS_ERR_INVALID, "internal: per-row outputs need the voc_out tail");
   const long long peak_ld = (long long)(Nld / POST_TW + 2);
   bool peak_parts_ready = false;  // post_conv_kernel left the per-workgroup maxima of the FINAL waveform
   if (vo) {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
@@ -457,13 +502,13 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     a.C = ch;
     a.y = wav;
     a.y_bs = (long long)Nld;
-    if (wav_i16 && !denoise) {
+    if (any_i16 && !denoise) {
       a.peak = reinterpret_cast<float*>(peak);
       a.peak_ld = peak_ld;
       peak_parts_ready = true;
     }
     ProfScope ps(ctx, w, KC_VOC_IO, 2.0 * (double)ch * 7 * (double)Lin * B);
-    ctx->kn[KN_POST_CONV].fetch_add(1, std::memory_order_relaxed);
+    kn_hit(ctx, KN_POST_CONV);
     const dim3 pg((Lin + POST_TW - 1) / POST_TW, B);
     if (a.x3) hipLaunchKernelGGL(HIP_KERNEL_NAME(post_conv_kernel<7, 3>), pg, dim3(256), 0, s, a);
     else if (a.x2) hipLaunchKernelGGL(HIP_KERNEL_NAME(post_conv_kernel<7, 2>), pg, dim3(256), 0, s, a);
@@ -491,7 +536,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     // ONE launch delivers the rows: to the caller's device buffers (pause before | samples | zeros up to the row stride), or to
     // the staging buffers the host copy reads (the float rows in place: zero tails behind a short row's samples)
     ProfScope ps(ctx, w, KC_SMALL, 0);
-    if (wav_i16 && !peak_parts_ready) {  // behind the denoiser: one peak per row, from the denoised rows
+    if (any_i16 && !peak_parts_ready) {  // behind the denoiser: one peak per row, from the denoised rows
       HIPCHECK(hipMemsetAsync(peak, 0, sizeof(unsigned) * B, s));
       hipLaunchKernelGGL(absmax_kernel, dim3(128, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, peak);
     }
@@ -502,18 +547,32 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     o.peak_ld = peak_parts_ready ? peak_ld : 1;
     o.peak_parts = peak_parts_ready ? 0 : 1;
     o.pad_before = pad0;
-    if (out_dev) {
+    bool any_out = false;
+    if (prow) {
+      o.per_row = 1;
+      for (int b = 0; b < B; ++b) {
+        const VocRow& r = prow[b];
+        o.pad_rows[b] = r.pad_before;
+        if (out_dev) {
+          o.f32_rows[b] = r.wav_f32; o.f_ld_rows[b] = r.wav_ld;
+          o.i16_rows[b] = r.wav_i16; o.i_ld_rows[b] = r.wav_ld;
+        } else if (r.wav_i16) {
+          o.i16_rows[b] = i16 + (size_t)b * ild; o.i_ld_rows[b] = (long long)ild;
+        }
+        any_out = any_out || o.f32_rows[b] || o.i16_rows[b];
+      }
+    } else if (out_dev) {
       if (wav_f32) { o.f32 = wav_f32; o.f_bs = wav_ld; o.f_ld = wav_ld; }
       if (wav_i16) { o.i16 = wav_i16; o.i_bs = wav_ld; o.i_ld = wav_ld; }
     } else {
       // (the float rows stay where they are: only a short row's tail up to the longest row is zeroed, in place)
       if (wav_i16) { o.i16 = i16; o.i_bs = (long long)ild; o.i_ld = (long long)ild; }
     }
-    if (o.f32 || o.i16) {
-      ctx->kn[KN_WAVE_OUT].fetch_add(1, std::memory_order_relaxed);
+    if (o.f32 || o.i16 || any_out) {
+      kn_hit(ctx, KN_WAVE_OUT);
       hipLaunchKernelGGL(wave_out_kernel, dim3(128, B), dim3(256), 0, s, o);
     }
-    if (!out_dev && wav_f32 && B > 1) hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
+    if (!out_dev && any_f32 && B > 1) hipLaunchKernelGGL(zero_tail_kernel, dim3(64, B), dim3(256), 0, s, wav, (long long)Nld, (long long)Nld, d_frames, hop);
     if (out_dev) {
       HIPCHECK(mi355_sync(s));
       HIPCHECK(hipGetLastError());
@@ -553,6 +612,38 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   }
   // host outputs: device -> the worker's pinned staging (async DMA) -> the caller's (pageable)
   // buffers; a pageable destination would make every hipMemcpyAsync a blocking staged copy
+  if (prow) {
+    // per-row destinations: a row travels with its OWN length (its caller's buffer is sized for its own frame count)
+    const size_t prl = (size_t)N + (size_t)pads;  // staging stride in samples
+    const size_t f32_b = any_f32 ? sizeof(float) * (size_t)B * (size_t)N : 0;
+    const size_t i16_b = any_i16 ? sizeof(short) * (size_t)B * prl : 0;
+    CHECK(reserve_pinned_out(w, f32_b + i16_b));
+    float* pf = (float*)w->pinned_out;
+    short* pi = (short*)(w->pinned_out + f32_b);
+    for (int b = 0; b < B; ++b) {
+      const VocRow& r = prow[b];
+      const size_t n = (size_t)mel->frames[b] * hop;
+      if (r.wav_f32 && n) HIPCHECK(hipMemcpyAsync(pf + (size_t)b * N, wav + (size_t)b * Nld, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+      if (r.wav_i16) HIPCHECK(hipMemcpyAsync(pi + (size_t)b * prl, i16 + (size_t)b * ild, sizeof(short) * (n + r.pad_before + r.pad_after), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(mi355_sync(s));
+    HIPCHECK(hipGetLastError());
+    drain.ok = true;
+    for (int b = 0; b < B; ++b) {
+      const VocRow& r = prow[b];
+      const size_t n = (size_t)mel->frames[b] * hop, p0 = (size_t)r.pad_before, rl = n + p0 + (size_t)r.pad_after;
+      if (r.wav_f32) {
+        std::memset(r.wav_f32, 0, sizeof(float) * p0);
+        std::memcpy(r.wav_f32 + p0, pf + (size_t)b * N, sizeof(float) * n);
+        std::memset(r.wav_f32 + p0 + n, 0, sizeof(float) * ((size_t)r.wav_ld - p0 - n));
+      }
+      if (r.wav_i16) {
+        std::memcpy(r.wav_i16, pi + (size_t)b * prl, sizeof(short) * rl);
+        std::memset(r.wav_i16 + rl, 0, sizeof(int16_t) * ((size_t)r.wav_ld - rl));
+      }
+    }
+    return 0;
+  }
   const size_t f32_bytes = wav_f32 ? sizeof(float) * (size_t)B * (size_t)N : 0;
   const size_t i16_bytes = wav_i16 ? sizeof(short) * (size_t)B * (size_t)rowlen : 0;
   CHECK(reserve_pinned_out(w, f32_bytes + i16_bytes));

@@ -7,6 +7,7 @@ struct ProfEvent {
   hipEvent_t a, b;
   int cls;
   double flop;
+  int kn, sub;  // kernel name (KName, -1 = a kernel without one) and a sub-key of the launch (its output rows / channels)
 };
 enum KClass { KC_RESBLOCK = 0, KC_UPSAMPLE, KC_VOC_IO, KC_GLOW_ENC_CONV, KC_GLOW_DEC_CONV, KC_SMALL, KC_MRF_NARROW, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_mfma.hifigan_upsample",
@@ -16,21 +17,25 @@ static const char* kclass_name[KC_COUNT] = {"conv_mfma.hifigan_resblock", "conv_
 
 // Launches per kernel NAME since the last mi355tts_profile_reset (always counted: one relaxed atomic add per launch) —
 // mi355tts_kernel_counts_json.  The class counters above cannot tell a kernel from the fallback that would take its place
-// (rb_group_kernel -> conv_group_kernel, rb_pair_group_kernel -> pair_group_kernel, wn_layer_kernel -> gate16 + lin16:
+// (rb_group_kernel -> conv_group_kernel, rb_pair_group_kernel -> pair_group_kernel:
 // same launch counts per class, same bits by design), so the device tests assert on these.
 enum KName {
   KN_CONV_MFMA = 0, KN_CONV_M128, KN_CONV_GROUP, KN_RB_CONV, KN_RB_GROUP, KN_RB_GROUP_SNAKE, KN_PAIR, KN_PAIR_GROUP, KN_RB_PAIR,
   KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_GATE16_WIDE, KN_LIN16,
-  KN_LIN16_LN, KN_LIN16_WIDE, KN_WN_LAYER, KN_WN_GATE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_COUNT
+  KN_LIN16_LN, KN_LIN16_WIDE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_ATTENTION, KN_COUNT
 };
 static const char* kname_name[KN_COUNT] = {
     "conv_mfma_kernel", "conv_mfma_kernel.m128", "conv_group_kernel", "rb_conv_kernel", "rb_group_kernel", "rb_group_kernel.snake",
     "resblock_pair_kernel", "pair_group_kernel", "rb_pair_kernel", "rb_pair_group_kernel", "conv_bf16_kernel", "conv_bf16_group_kernel",
     "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "gate16_kernel.wide", "lin16_kernel", "lin16_kernel.ln", "lin16_kernel.wide",
-    "wn_layer_kernel", "wn_layer_kernel.gate_only", "glow_tail_kernel", "oproj_ln_kernel", "post_conv_kernel", "wave_out_kernel"};
+    "glow_tail_kernel", "oproj_ln_kernel", "post_conv_kernel", "wave_out_kernel", "attention_mfma_kernel"};
 // the launch helpers without a context argument (launch_conv_k, launch_group_k) count through this: set by run_plan / run_group
 static thread_local std::atomic<long long>* g_kn = nullptr;
+// the kernel name (and launch sub-key: output rows / channels) of the launch inside the running ProfScope: the scope's
+// destructor files its event pair under them (mi355tts_profile_kernels_json: durations per kernel NAME, not only per class)
+static thread_local int g_last_kn = -1, g_last_sub = 0;
 static inline void kn_add(int k) {
+  g_last_kn = k;
   if (g_kn) g_kn[k].fetch_add(1, std::memory_order_relaxed);
 }
 
@@ -42,8 +47,10 @@ static inline void kn_add(int k) {
 // (the default slack of 50 us would add that much to every wake-up) and restored afterwards.
 // MI355TTS_SYNC_MODE: 0 = hipStreamSynchronize, 1 = blocking event, 2 = query + 20 us sleep (no spin phase, default slack),
 // 3 = adaptive.  Read once.
+// Option "sync_mode" (mi355tts_set_option; process-wide, like the environment variable that seeds it) selects the mode at run time.
+static std::atomic<int> g_sync_mode{[] { const char* e = std::getenv("MI355TTS_SYNC_MODE"); return e ? std::atoi(e) : 3; }()};
 static hipError_t mi355_sync(hipStream_t s) {
-  static const int mode = [] { const char* e = std::getenv("MI355TTS_SYNC_MODE"); return e ? std::atoi(e) : 3; }();
+  const int mode = g_sync_mode.load(std::memory_order_relaxed);
   if (mode == 1) {
     // one blocking event per (thread, device): an event belongs to the device that was current when it was created
     constexpr int MAXDEV = 16;
@@ -75,8 +82,10 @@ static hipError_t mi355_sync(hipStream_t s) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 60000) break;
     }
+    // the calling thread's timer slack: lowered for the duration of this wait only and restored — and left alone where the
+    // process may not change it (a seccomp filter that denies prctl: the sleeps then keep the default slack)
     const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
-    if (slack > 1000) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    const bool lowered = slack > 1000 && prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0) == 0;
     hipError_t e;
     for (;;) {
       e = hipStreamQuery(s);
@@ -84,11 +93,15 @@ static hipError_t mi355_sync(hipStream_t s) {
       struct timespec ts = {0, 20000};
       nanosleep(&ts, nullptr);
     }
-    if (slack > 1000) prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+    if (lowered) prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
     return e;
   }
   return hipStreamSynchronize(s);
 }
+
+#ifndef MI355TTS_CALL_COALESCE_DEFAULT
+#define MI355TTS_CALL_COALESCE_DEFAULT 0  // lanes of host_join.h's whole-call coalescing (0 = off)
+#endif
 
 struct Worker {
   hipStream_t stream = nullptr;
@@ -102,6 +115,9 @@ struct Worker {
   std::vector<ProfEvent> events;
   // profiled FLOP of the launches that follow = the padded-batch figure x this (sum of the rows' real lengths / (B x longest))
   double flop_scale = 1.0;
+  // this worker's launches are neither profiled nor counted per kernel name (the dispatch self-check's own launches are not a
+  // caller's: a worker-local switch, so concurrent calls on the context keep their samples and counts)
+  bool quiet = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   // side streams for the independent MRF branches of a HiFi-GAN stage
   hipStream_t aux[2] = {nullptr, nullptr};
@@ -112,12 +128,6 @@ struct Worker {
   bool o_glow_fuse = true, o_gate16 = true, o_rb_conv = true, o_rb_pair = true, o_group_promote = true;
   bool o_snake = true;  // grouped launches whose workgroups are all resident go out in the snake order (group_snake_order)
   int o_gate16_wide = 512;  // wide passes (at least this many 16-row tiles; 0 = never): two row tiles per gate16 workgroup
-  bool o_wn_layer = false;  // this call's decoder runs its WaveNet layers as column-owner launches (wn_layer.h)
-  // option "glow_priority": the acoustic model's ~140 small launches of a fused call go out on a HIGH-priority stream of
-  // their own (created on first use), the vocoder follows on `stream` behind `ev_glow`
-  hipStream_t gstream = nullptr;
-  hipEvent_t ev_glow = nullptr;
-  int gprio = 0;  // the option value gstream was created for (1 = highest, 2 = lowest priority)
 };
 
 struct mi355tts_ctx {
@@ -143,37 +153,33 @@ struct mi355tts_ctx {
   // GlowTTS column-owner launches (coltile.h: block tails, conv_o + LayerNorm) AND the whole-tile-in-LDS convs of
   // gate16.h's lin16_kernel (FFN / duration predictor / prenet / 1 x 1 convs, LayerNorm prologues): 0 = the generic tiles
   std::atomic<bool> glow_fuse{true};
-  // GlowTTS decoder: one column-owner launch per WaveNet layer (wn_layer.h) — the throughput form; same bits as the
-  // gate16 + lin16 chain.  0 = never, 1 = when the pass is wide (>= wn_layer_min_tiles 16-column tiles: padded batches,
-  // coalesced passes) or other calls are in flight on the context, 2 = always.  Off by default: on MI355X the column owners
-  // lose under every load measured (a launch holds its hardware queue for its DURATION: profiles/r05_wn_layer_ab.txt)
-  std::atomic<int> wn_layer{0};
-  std::atomic<int> wn_layer_min_tiles{48};
   std::atomic<bool> voc_out{true};    // conv_post + peak and the delivery of the rows as two dedicated launches (voc_out.h); 0 = round 4's ten
   std::atomic<bool> mrf_small{true};  // narrow stages (C = 8 / 16) as one fused launch per stage (mrf_small.h)
   std::atomic<bool> mrf_group{true};  // grouped launches of the MRF chains' same-geometry convs (hifigan_forward.h)
   std::atomic<bool> rb_conv{true};    // grouped 128-row launches on the continuous-stream tile (rb_conv.h; same bits)
   std::atomic<bool> group_promote{true};  // batch-1 ResBlock steps move to the 128-row tile when the snake deal is balanced (promote_group_plans)
   // Grouped launches whose workgroups are all resident at once are laid out as a snake over the dispatcher's rounds
-  // (group_snake_order).  That order — and the promotion rule that relies on it — encodes an OBSERVED dispatcher rule (workgroup i
-  // -> CU i mod #CUs); mi355tts_dispatch_selfcheck times it against the plain order on this device (first 'high'-class vocoder
-  // load) and turns both off where the snake does not win (a partitioned GPU, another CU count, a firmware that deals differently).
+  // (group_snake_order).  That order encodes an OBSERVED dispatcher rule (workgroup i -> CU i mod #CUs);
+  // mi355tts_dispatch_selfcheck times it against the plain order on this device (first 'high'-class vocoder load) and turns
+  // it off where it does not win (a partitioned GPU, another CU count, a firmware that deals differently).  The ORDER of a
+  // launch's workgroups never changes a result; the promotion rule (which picks the TILE, i.e. the summation order) is
+  // decided from the CU count and the geometry alone and is never touched by a timing.
   std::atomic<bool> group_snake{true};
-  std::atomic<int> selfcheck_state{0};  // 0 = not run, 1 = snake kept, 2 = snake and promotion disabled, 3 = skipped / failed
+  std::atomic<int> selfcheck_state{0};  // 0 = not run, 4 = running, 1 = snake kept, 2 = snake order disabled, 3 = skipped / failed
   float selfcheck_plain_us = 0.f, selfcheck_snake_us = 0.f;
   std::atomic<bool> rb_pair{true};    // fused ResBlock steps (64 / 32 channels) on the 4-wave tile without a k-split (rb_pair.h)
-  // mi355tts_synthesize: GlowTTS on a high-priority stream of the call's worker (see Worker::gstream).  The hardware queues
-  // run one kernel at a time each and the runtime maps all bulk streams onto 4 of them: a call's chain of ~140 small
-  // dependent launches otherwise advances one launch per 200 us ResBlock kernel of the stream it shares a queue with
-  std::atomic<int> glow_priority{0};
-  // concurrent batch-1 mi355tts_synthesize calls share ONE GlowTTS pass (host_join.h): the callers waiting when a pass
-  // starts become its rows.  Off by default: measured neutral to -1 % on the 'high' vocoder (profiles/NOTES.md)
-  std::atomic<bool> glow_coalesce{false};
+  // Whole-call coalescing (host_join.h): concurrent batch-1 mi355tts_synthesize calls become the rows of fused padded calls,
+  // at most `call_coalesce` of them in flight (0 = off).  A caller that finds a lane free while other passes are in flight
+  // gathers for up to `call_coalesce_window_us`; a lone caller never waits.
+  std::atomic<int> call_coalesce{MI355TTS_CALL_COALESCE_DEFAULT};
+  std::atomic<int> call_coalesce_window_us{300};
   std::mutex join_mu;
   std::condition_variable join_cv;
-  std::vector<struct GlowJoinReq*> join_q;
-  std::vector<const struct GlowJoinReq*> join_leaders;  // the leaders of the passes in flight (under join_mu)
-  long long join_passes = 0, join_rows = 0;  // under join_mu
+  std::vector<struct CallReq*> join_q;  // waiting requests in arrival order (under join_mu, like everything below)
+  int join_inflight = 0, join_rows_inflight = 0;  // fused passes in flight and the rows they carry
+  bool join_gathering = false;                    // a leader-to-be is inside its gather window
+  long long join_arrivals = 0;
+  long long join_passes = 0, join_rows = 0;  // counters since the context was created (mi355tts_coalesce_stats)
   // recycled device blocks for the mel result objects: hipMalloc/hipFree synchronise
   // the whole device, which would serialise the concurrent per-utterance streams
   std::vector<std::pair<void*, size_t>> mel_pool;
@@ -183,6 +189,7 @@ struct mi355tts_ctx {
     long long launches = 0;
     double ms = 0, flop = 0;
   } prof[KC_COUNT];
+  std::map<std::pair<int, int>, Acc> prof_kn[KC_COUNT];  // per class: (kernel name, sub-key) -> the same sums
   std::atomic<long long> kn[KN_COUNT] = {};  // launches per kernel name (KName)
 };
 
@@ -197,6 +204,11 @@ struct mi355tts_mel {
   size_t raw_bytes = 0;  // allocation size of raw / voc (pool bookkeeping)
 };
 
+static inline void kn_hit(mi355tts_ctx* ctx, int k) {
+  g_last_kn = k;
+  ctx->kn[k].fetch_add(1, std::memory_order_relaxed);
+}
+
 // The kernel-selection options as a call sees them: taken when the call checks its worker out, so EVERY entry point (the op /
 // bench entry points and the denoiser bias too, not only glow_run / hifigan_run) launches under the context's current options
 // and never under what the worker's previous call left behind.
@@ -208,7 +220,6 @@ static void snapshot_options(mi355tts_ctx* ctx, Worker* w) {
   w->o_group_promote = ctx->group_promote.load();
   w->o_snake = ctx->group_snake.load();
   w->o_gate16_wide = ctx->gate16_wide.load();
-  w->o_wn_layer = false;
 }
 
 static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
@@ -257,6 +268,10 @@ static void drain_profile(mi355tts_ctx* ctx, Worker* w) {
       ctx->prof[ev.cls].launches++;
       ctx->prof[ev.cls].ms += ms;
       ctx->prof[ev.cls].flop += ev.flop;
+      mi355tts_ctx::Acc& k = ctx->prof_kn[ev.cls][std::make_pair(ev.kn, ev.sub)];
+      k.launches++;
+      k.ms += ms;
+      k.flop += ev.flop;
     }
     w->event_pool.emplace_back(ev.a, ev.b);
   }

@@ -10,7 +10,7 @@ struct ProfScope {
   ProfEvent ev;
   hipStream_t st;
   ProfScope(mi355tts_ctx* c, Worker* wk, int cls, double flop, hipStream_t stream = nullptr)
-      : ctx(c), w(wk), on(c->profiling.load()), st(stream ? stream : wk->stream) {
+      : ctx(c), w(wk), on(c->profiling.load() && !wk->quiet), st(stream ? stream : wk->stream) {
     if (!on) return;
     if (!w->event_pool.empty()) {
       ev.a = w->event_pool.back().first;
@@ -24,10 +24,14 @@ struct ProfScope {
     }
     ev.cls = cls;
     ev.flop = flop * wk->flop_scale;
+    g_last_kn = -1;
+    g_last_sub = 0;
     hipEventRecord(ev.a, st);
   }
   ~ProfScope() {
     if (!on) return;
+    ev.kn = g_last_kn;
+    ev.sub = g_last_sub;
     hipEventRecord(ev.b, st);
     w->events.push_back(ev);
   }
@@ -303,12 +307,13 @@ static int run_plan(mi355tts_ctx* ctx, Worker* w, const ConvPlan& p, hipStream_t
   if (p.empty) return 0;
   hipStream_t s = stream ? stream : w->stream;
   ProfScope ps(ctx, w, p.cls, p.flop, s);
+  g_last_sub = p.a.rows;
   const ConvArgs& a = p.a;
   const int MB = p.MB, shape = p.shape;
   const dim3 grid = p.grid;
   int rc = 0;
   g_rb_conv_on = w->o_rb_conv;
-  g_kn = ctx->kn;
+  g_kn = w->quiet ? nullptr : ctx->kn;
   if (p.bf16) {
     kn_add(KN_CONV_BF16);
 #define BF16_LAUNCH_T(KK, TT)                                                                                                      \
@@ -506,11 +511,12 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
   const dim3 grid(off_wg, 1, p0.grid.z);
   const int k0 = plans[ord[0]].K, k1 = plans[ord[1]].K, k2 = plans[ord[2]].K;
   const bool taps_ok = (k0 == 11 && k1 == 7 && k2 == 3) || (k0 == 7 && k1 == 5 && k2 == 3);
-  g_kn = ctx->kn;
+  g_kn = w->quiet ? nullptr : ctx->kn;
   if (p0.bf16) {
     if (!taps_ok) return 1;
-    kn_add(KN_CONV_BF16_GROUP);
     ProfScope ps(ctx, w, p0.cls, flop, s);
+    g_last_sub = p0.a.rows;
+    kn_add(KN_CONV_BF16_GROUP);
 #define BF16_GROUP_T(KA, KB, KC, TT)                                                                                                                \
   if (p0.shape == BF_A)                                                                                                                            \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_bf16_group_kernel<KA, KB, KC, 1, 4, 4, 1, ConvCfg<KA>::HALO, ConvCfg<KB>::HALO, ConvCfg<KC>::HALO, TT>), \
@@ -543,6 +549,7 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
                         (p0.shape == TILE_NB2 && p0.MB == 2) || p0.shape == TILE_M128;
   if (!shape_ok || !taps_ok) return 1;
   ProfScope ps(ctx, w, p0.cls, flop, s);
+  g_last_sub = p0.a.rows;
   // The 128-row tile with the continuous matrix stream (rb_conv.h; same bits as the chunked tile) where the launch is
   // what it was written for: plain ResBlock convs (bias, optional residual), taps 11 / 7 / 3, dilation within its halos.
   if (p0.shape == TILE_M128 && k0 == 11 && !rb_off && w->o_rb_conv) {
@@ -635,9 +642,10 @@ static void plan_pair(const DevConv& c1, const DevConv& c2, const float* x, floa
 }
 static int run_pair(mi355tts_ctx* ctx, Worker* w, const PairPlan& p, hipStream_t s) {
   ProfScope ps(ctx, w, KC_RESBLOCK, p.flop, s);
+  g_last_sub = p.C;
   const PairArgs& a = p.a;
   const dim3 grid = p.grid;
-  g_kn = ctx->kn;
+  g_kn = w->quiet ? nullptr : ctx->kn;
   kn_add(p.bf16 ? KN_PAIR_BF16 : (w->o_rb_pair && p.rb) ? KN_RB_PAIR : KN_PAIR);
   if (p.bf16) {
 #define PAIR16_LAUNCH(KK, TT)                                                                                                                  \
@@ -706,7 +714,8 @@ static int run_pair_group(mi355tts_ctx* ctx, Worker* w, const PairPlan* plans, i
   g.off[3] = off_wg;
   const dim3 grid(off_wg, 1, p0.grid.z);
   ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
-  g_kn = ctx->kn;
+  g_last_sub = p0.C;
+  g_kn = w->quiet ? nullptr : ctx->kn;
   kn_add(p0.bf16 ? KN_PAIR_BF16_GROUP : (w->o_rb_pair && p0.rb) ? KN_RB_PAIR_GROUP : KN_PAIR_GROUP);
   if (p0.bf16 == 3) {
     if (p0.C == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_bf16_group_kernel<11, 7, 3, 1, P16_WN32, P16_NB32, 3>), grid, dim3(64 * P16_WN32), 0, s, g);
@@ -757,16 +766,16 @@ static int run_mrf_small(mi355tts_ctx* ctx, Worker* w, const MrfStage& ms, const
   ProfScope ps(ctx, w, KC_MRF_NARROW, 2.0 * ms.mac_per_col * (double)Lmax * B, s);
   static const bool mrf8_off = [] { const char* e = std::getenv("MI355TTS_NO_MRF8"); return e && std::atoi(e) != 0; }();
   if (ms.C == 16) {
-    ctx->kn[KN_MRF_SMALL].fetch_add(1, std::memory_order_relaxed);
+    kn_hit(ctx, KN_MRF_SMALL);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<16, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   } else if (!mrf8_off) {
     // 8 channels: the 4x4x1 16-block MFMA (no padding rows), its own fragment packing; two waves per tile
     a.w = arena + ms.w8_off;
     a.tab = reinterpret_cast<const int*>(arena + ms.t8_off);
-    ctx->kn[KN_MRF8].fetch_add(1, std::memory_order_relaxed);
+    kn_hit(ctx, KN_MRF8);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf8_kernel<T, 3, 7, 11>), grid, dim3(128), 0, s, a);
   } else {
-    ctx->kn[KN_MRF_SMALL].fetch_add(1, std::memory_order_relaxed);
+    kn_hit(ctx, KN_MRF_SMALL);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mrf_small_kernel<8, T, 4, 3, 7, 11>), grid, dim3(256), 0, s, a);
   }
   return 0;
@@ -825,7 +834,7 @@ static int run_gate16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const Conv
   }
 #undef GATE16_J
 #undef GATE16_LAUNCH
-  ctx->kn[wide ? KN_GATE16_WIDE : KN_GATE16].fetch_add(1, std::memory_order_relaxed);
+  kn_hit(ctx, wide ? KN_GATE16_WIDE : KN_GATE16);
   return 0;
 }
 
@@ -890,42 +899,7 @@ static int run_lin16(mi355tts_ctx* ctx, Worker* w, const DevConv& c, const ConvA
   else if (c.K == 5 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<5, 6, 2>), grid, dim3(512), 0, s, g);
   else if (c.K == 1 && c.l16_J == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(lin16_kernel<1, 6, 2>), grid, dim3(512), 0, s, g);
   else return 1;
-  ctx->kn[wide ? KN_LIN16_WIDE : ln ? KN_LIN16_LN : KN_LIN16].fetch_add(1, std::memory_order_relaxed);
-  return 0;
-}
-
-// ---- one WaveNet layer of the GlowTTS decoder as ONE column-owner launch (wn_layer.h): gate conv `in` + gate + res_skip conv
-// `rs` (rs == nullptr: the block's last layer — its res_skip runs in glow_tail_kernel — writes the gated activations to `acts`).
-// Returns 1 when the shapes are not the kernel's (the caller runs gate16 + lin16), 0 when launched.  Same bits as those two.
-static bool wn_layer_shape_ok(const DevConv& in, const DevConv* rs, int H) {
-  if (in.g16_J != 6 || H != 192 || in.Cin != H || (in.K != 5 && in.K != 3)) return false;
-  if (rs && (rs->l16_J != 6 || rs->K != 1 || rs->Cin != H || rs->Cout != 2 * H)) return false;
-  return true;
-}
-static int run_wn_layer(mi355tts_ctx* ctx, Worker* w, const DevConv& in, const DevConv* rs, const float* arena, const float* x, float* x_out,
-                        float* acts, float* skip, int accum, long long bs, int ld, const int* len, int host_len, int dil, int pad,
-                        const float* cond, long long cond_bs, int H, int B, int n_max) {
-  if (!wn_layer_shape_ok(in, rs, H) || dil != 1 || pad != (in.K - 1) / 2 || ld % 4 || n_max <= 0 || x == x_out) return 1;
-  WnLayerArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.x = x; a.x_out = x_out; a.bs = bs; a.ld = ld;
-  if (B == 1 && host_len >= 0) { a.len = nullptr; a.len_const = host_len; } else { a.len = len; }
-  a.len_mul = 1;
-  a.gw = in.g16_w; a.gb = in.g16_b;
-  if (rs) { a.rw = arena + rs->l16_w_off; a.rb = arena + rs->l16_b_off; }
-  a.acts = acts; a.skip = skip; a.accum = accum; a.pad = pad; a.cond = cond; a.cond_bs = cond_bs;
-  const double mac = (double)in.Cout * in.Cin * in.K + (rs ? (double)rs->Cout * rs->Cin : 0.0);
-  ProfScope ps(ctx, w, KC_GLOW_DEC_CONV, 2.0 * mac * (double)n_max * B);
-  const dim3 grid((n_max + WN_T - 1) / WN_T, B);
-  hipStream_t s = w->stream;
-  ctx->kn[rs ? KN_WN_LAYER : KN_WN_GATE].fetch_add(1, std::memory_order_relaxed);
-  if (in.K == 5) {
-    if (rs) hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<5, 6, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<5, 6, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (rs) hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<3, 6, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wn_layer_kernel<3, 6, false>), grid, dim3(256), 0, s, a);
-  }
+  kn_hit(ctx, wide ? KN_LIN16_WIDE : ln ? KN_LIN16_LN : KN_LIN16);
   return 0;
 }
 

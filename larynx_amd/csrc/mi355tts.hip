@@ -13,6 +13,7 @@
 #include <sys/prctl.h>
 #include <atomic>
 #include <condition_variable>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -36,7 +37,6 @@
 #include "mrf_small.h"
 #include "gate16.h"
 #include "coltile.h"
-#include "wn_layer.h"
 #include "voc_out.h"
 #include "small_kernels.h"
 #include "weights_pack.h"
@@ -84,8 +84,6 @@ extern "C" void mi355tts_destroy(mi355tts_ctx* ctx) {
       if (w->ev_join[i]) hipEventDestroy(w->ev_join[i]);
     }
     if (w->ev_fork) hipEventDestroy(w->ev_fork);
-    if (w->gstream) hipStreamDestroy(w->gstream);
-    if (w->ev_glow) hipEventDestroy(w->ev_glow);
     if (w->arena) hipFree(w->arena);
     if (w->pinned) hipHostFree(w->pinned);
     if (w->pinned_out) hipHostFree(w->pinned_out);
@@ -850,37 +848,37 @@ static int synthesize_impl(mi355tts_ctx* ctx, int glow, int vocoder, const int64
   CHECK(glow_precheck(gm, g, &Pmax));
   CHECK(hifigan_precheck(ctx, hm, vocoder, nullptr, B, gm->hp.mel_channels, -1, v));  // incl. the one-time denoiser bias
   HIPCHECK(hipSetDevice(ctx->device));
-  Worker* w = nullptr;
-  CHECK(acquire_worker(ctx, &w));
-  WorkerGuard guard{ctx, w};
-  static const bool no_coalesce = [] { const char* e = std::getenv("MI355TTS_NO_GLOW_COALESCE"); return e && std::atoi(e) != 0; }();
-  if (B == 1 && !noise && !speaker_ids && !no_coalesce && ctx->glow_coalesce.load() && id_lens[0] <= ATTM_MAXP) {
-    // a batch-1 call: its GlowTTS pass is shared with whichever other batch-1 calls are waiting right now (host_join.h)
-    GlowJoinReq req;
+  static const bool no_coalesce = [] { const char* e = std::getenv("MI355TTS_NO_CALL_COALESCE"); return e && std::atoi(e) != 0; }();
+  const int lanes = no_coalesce ? 0 : ctx->call_coalesce.load();
+  if (lanes > 0 && B == 1 && !noise && !speaker_ids && id_lens[0] <= ATTM_MAXP && ctx->voc_out.load() && !ctx->serial_branches.load()) {
+    // a batch-1 call: it rides a fused padded call with whichever other batch-1 calls are waiting right now (host_join.h)
+    CallReq req;
     req.gm = gm;
+    req.hm = hm;
+    req.vocoder = vocoder;
     req.ids = ids;
     req.len = id_lens[0];
     req.noise_scale = noise_scale;
     req.length_scale = length_scale;
     req.seed = seed;
     req.audio = audio;
-    req.flags = g.flags;
-    CHECK(glow_join(ctx, w, req));
-    mi355tts_mel view;
-    glow_join_view(req, &view);
-    struct BatchDrop {
-      Worker* w;
-      std::shared_ptr<GlowBatch>* b;
-      ~BatchDrop() {
-        mi355_sync(w->stream);  // the row's blocks go back to the pool with the last caller: nothing of ours may still read them
-        b->reset();
-      }
-    } drop{w, &req.batch};
-    frames_out[0] = view.frames[0];
-    if (req.batch->ready) HIPCHECK(hipStreamWaitEvent(w->stream, req.batch->ready, 0));
-    CHECK(hifigan_precheck(ctx, hm, vocoder, view.frames.data(), 1, view.M, view.max_frames, v));
-    return hifigan_run(ctx, w, hm, &view, v);
+    req.flags = flags & (MI355TTS_IN_DEVICE | MI355TTS_OUT_DEVICE);
+    req.denoiser_strength = denoiser_strength;
+    req.out.wav_f32 = wav_f32;
+    req.out.wav_i16 = wav_i16;
+    req.out.wav_ld = wav_ld;
+    req.out.pad_before = pad_before;
+    req.out.pad_after = pad_after;
+    const int jr = call_join(ctx, req, lanes);
+    if (jr <= 0) {
+      frames_out[0] = req.frames;
+      return jr;
+    }
+    // jr == 1: the shared pass failed; this call runs alone below and reports its own result
   }
+  Worker* w = nullptr;
+  CHECK(acquire_worker(ctx, &w));
+  WorkerGuard guard{ctx, w};
   mi355tts_mel* mel = nullptr;
   struct MelDrop {
     Worker* w;
@@ -891,48 +889,8 @@ static int synthesize_impl(mi355tts_ctx* ctx, int glow, int vocoder, const int64
       mel_destroy(m);
     }
   } drop{w, nullptr};
-  const int gprio = ctx->glow_priority.load();
-  if (gprio) {
-    if (w->gstream && w->gprio != gprio) {  // the option changed since this worker's stream was made: recreate it
-      mi355_sync(w->gstream);
-      hipStreamDestroy(w->gstream);
-      w->gstream = nullptr;
-    }
-    if (!w->gstream) {
-      int least = 0, greatest = 0;
-      HIPCHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      hipStream_t gs = nullptr;
-      HIPCHECK(hipStreamCreateWithPriority(&gs, hipStreamNonBlocking, gprio == 2 ? least : greatest));
-      if (!w->ev_glow) {
-        const hipError_t e = hipEventCreateWithFlags(&w->ev_glow, hipEventDisableTiming);
-        if (e != hipSuccess) {  // stream and event exist together or not at all
-          w->ev_glow = nullptr;
-          hipStreamDestroy(gs);
-          return fail(MI355TTS_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
-        }
-      }
-      w->gstream = gs;
-      w->gprio = gprio;
-    }
-    hipStream_t bulk = w->stream;
-    w->stream = w->gstream;  // the worker belongs to this call: everything glow_run queues goes to the priority stream
-    const int rc = glow_run(ctx, w, gm, g, Pmax, false, &mel);
-    w->stream = bulk;
-    if (rc != 0) {
-      mi355_sync(w->gstream);
-      return rc;
-    }
-    drop.m = mel;  // from here on every exit frees the mel (after draining the bulk stream)
-    hipError_t e = hipEventRecord(w->ev_glow, w->gstream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(bulk, w->ev_glow, 0);
-    if (e != hipSuccess) {
-      mi355_sync(w->gstream);  // the mel's producers run on the priority stream, which MelDrop does not drain
-      return fail(MI355TTS_ERR_HIP, "glow_priority hand-over: %s", hipGetErrorString(e));
-    }
-  } else {
-    CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
-    drop.m = mel;
-  }
+  CHECK(glow_run(ctx, w, gm, g, Pmax, false, &mel));
+  drop.m = mel;
   for (int b = 0; b < B; ++b) frames_out[b] = mel->frames[b];
   CHECK(hifigan_precheck(ctx, hm, vocoder, mel->frames.data(), B, mel->M, mel->max_frames, v));
   return hifigan_run(ctx, w, hm, mel, v);
@@ -1235,7 +1193,14 @@ extern "C" int mi355tts_bench_conv1d(mi355tts_ctx* ctx, int B, int Cin, int Cout
 // Runs once per context, on the first load of a vocoder with a >= 256-channel stage (or on request); ~15 ms.
 static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
   int expected = 0;
-  if (!ctx->selfcheck_state.compare_exchange_strong(expected, 3)) return 0;  // someone ran (or is running) it
+  if (!ctx->selfcheck_state.compare_exchange_strong(expected, 4)) return 0;  // someone ran (or is running: state 4) it
+  struct Skipped {  // every early exit below leaves "skipped" behind
+    std::atomic<int>& st;
+    ~Skipped() {
+      int running = 4;
+      st.compare_exchange_strong(running, 3);
+    }
+  } skipped{ctx->selfcheck_state};
   {
     const char* e = std::getenv("MI355TTS_NO_SELFCHECK");
     hipDeviceProp_t prop;
@@ -1282,10 +1247,11 @@ static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
     a.in_slope = 0.1f;
     CHECK(plan_conv(cv[m], a, EPI_LINEAR, 1, L, KC_RESBLOCK, 1024, L, &plans[m], 0));
   }
-  const bool prof = ctx->profiling.load();
-  ctx->profiling = false;
-  long long kn_before[KN_COUNT];
-  for (int i = 0; i < KN_COUNT; ++i) kn_before[i] = ctx->kn[i].load(std::memory_order_relaxed);
+  struct Quiet {  // the check's launches are not a caller's: neither profiled nor counted (worker-local)
+    Worker* w;
+    ~Quiet() { w->quiet = false; }
+  } quiet{w};
+  w->quiet = true;
   w->o_group_promote = true;
   w->o_rb_conv = true;
   promote_group_plans(ctx, w, pp, 3);
@@ -1315,22 +1281,21 @@ static int dispatch_selfcheck_run(mi355tts_ctx* ctx) {
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
   }
-  ctx->profiling = prof;
-  for (int i = 0; i < KN_COUNT; ++i) ctx->kn[i].store(kn_before[i], std::memory_order_relaxed);  // (the check's launches are not the caller's)
-  if (rc != 0) return rc < 0 ? rc : 0;  // state stays 3: skipped
+  if (rc != 0) return rc < 0 ? rc : 0;  // state becomes 3: skipped
   ctx->selfcheck_plain_us = us[0];
   ctx->selfcheck_snake_us = us[1];
   if (us[1] > 1.02f * us[0]) {
+    // only the ORDER option: it cannot change a result.  The promotion rule picks the tile (= the summation order) and stays
+    // a function of the CU count and the geometry, whatever a timing on a busy device says
     ctx->group_snake = false;
-    ctx->group_promote = false;
     ctx->selfcheck_state = 2;
   } else {
     ctx->selfcheck_state = 1;
   }
   return 0;
 }
-// state: 0 = not run, 1 = the snake order is kept, 2 = the snake order and the promotion rule were switched off on this device,
-// 3 = skipped (MI355TTS_NO_SELFCHECK, the promotion rule declines the geometry on this CU count, emulator); the two times are
+// state: 0 = not run, 4 = running on another thread, 1 = the snake order is kept, 2 = the snake order was switched off on this
+// device (option "group_snake"; results are the same bits either way), 3 = skipped (MI355TTS_NO_SELFCHECK, the promotion rule declines the geometry on this CU count, emulator); the two times are
 // microseconds per grouped launch (0 when skipped)
 extern "C" int mi355tts_dispatch_selfcheck(mi355tts_ctx* ctx, int* state, float* plain_us, float* snake_us) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
@@ -1363,8 +1328,12 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->gate16 = value != 0;
     return 0;
   }
-  if (std::strcmp(name, "glow_coalesce") == 0) {
-    ctx->glow_coalesce = value != 0;
+  if (std::strcmp(name, "call_coalesce") == 0) {
+    ctx->call_coalesce = value < 0 ? 0 : value;
+    return 0;
+  }
+  if (std::strcmp(name, "call_coalesce_window_us") == 0) {
+    ctx->call_coalesce_window_us = value < 0 ? 0 : value;
     return 0;
   }
   if (std::strcmp(name, "glow_fuse") == 0) {
@@ -1391,10 +1360,6 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->rb_pair = value != 0;
     return 0;
   }
-  if (std::strcmp(name, "glow_priority") == 0) {
-    ctx->glow_priority = value;
-    return 0;
-  }
   if (std::strcmp(name, "gate16_wide") == 0) {
     ctx->gate16_wide = value < 0 ? 0 : value;
     return 0;
@@ -1403,20 +1368,18 @@ extern "C" int mi355tts_set_option(mi355tts_ctx* ctx, const char* name, int valu
     ctx->voc_out = value != 0;
     return 0;
   }
-  if (std::strcmp(name, "wn_layer") == 0) {
-    ctx->wn_layer = value;
-    return 0;
-  }
-  if (std::strcmp(name, "wn_layer_min_tiles") == 0) {
-    ctx->wn_layer_min_tiles = value;
-    return 0;
-  }
   if (std::strcmp(name, "serial_branches") == 0) {
     ctx->serial_branches = value != 0;
     return 0;
   }
+  if (std::strcmp(name, "sync_mode") == 0) {  // process-wide: how a caller thread waits for its stream (host_context.h, mi355_sync)
+    if (value < 0 || value > 3) return fail(MI355TTS_ERR_INVALID, "sync_mode %d outside [0, 3]", value);
+    g_sync_mode.store(value, std::memory_order_relaxed);
+    return 0;
+  }
   return fail(MI355TTS_ERR_INVALID, "unknown option '%s'", name);
 }
+extern "C" int mi355tts_call_coalesce_default(void) { return MI355TTS_CALL_COALESCE_DEFAULT; }
 extern "C" int mi355tts_coalesce_stats(mi355tts_ctx* ctx, int64_t* passes, int64_t* rows) {
   if (!ctx || !passes || !rows) return fail(MI355TTS_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ctx->join_mu);
@@ -1428,6 +1391,7 @@ extern "C" int mi355tts_profile_reset(mi355tts_ctx* ctx) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& a : ctx->prof) a = mi355tts_ctx::Acc();
+  for (auto& m : ctx->prof_kn) m.clear();
   for (auto& k : ctx->kn) k.store(0, std::memory_order_relaxed);
   return 0;
 }
@@ -1472,6 +1436,36 @@ extern "C" int mi355tts_profile_event_overhead(mi355tts_ctx* ctx, int pairs, dou
   if (e != hipSuccess) return fail(MI355TTS_ERR_HIP, "event overhead: %s", hipGetErrorString(e));
   std::sort(el.begin(), el.end());
   *us_out = 1000.0 * (double)el[el.size() / 2];
+  return 0;
+}
+// The same sums per kernel NAME and launch sub-key (output rows of a conv launch / channels of a fused pair): {"class": {"name/sub":
+// {"launches": n, "ms": t, "flop": f}, ...}, ...}; launches of kernels without a counted name are filed under "-".  bench.py's
+// `roofline.by_kernel` (a driver record on an unknown box can then be compared with the builder's kernel by kernel).
+extern "C" int mi355tts_profile_kernels_json(mi355tts_ctx* ctx, char* buf, int cap) {
+  if (!ctx || !buf || cap <= 2) return fail(MI355TTS_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::string s = "{";
+  bool first_cls = true;
+  for (int i = 0; i < KC_COUNT; ++i) {
+    if (ctx->prof_kn[i].empty()) continue;
+    s += first_cls ? "\"" : ", \"";
+    first_cls = false;
+    s += kclass_name[i];
+    s += "\": {";
+    bool first = true;
+    for (const auto& kv : ctx->prof_kn[i]) {
+      char tmp[256];
+      const int kn = kv.first.first;
+      std::snprintf(tmp, sizeof(tmp), "%s\"%s/%d\": {\"launches\": %lld, \"ms\": %.6f, \"flop\": %.6e}", first ? "" : ", ",
+                    kn >= 0 && kn < KN_COUNT ? kname_name[kn] : "-", kv.first.second, kv.second.launches, kv.second.ms, kv.second.flop);
+      s += tmp;
+      first = false;
+    }
+    s += "}";
+  }
+  s += "}";
+  if ((int)s.size() + 1 > cap) return fail(MI355TTS_ERR_TOO_SMALL, "profile buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
   return 0;
 }
 extern "C" int mi355tts_profile_json(mi355tts_ctx* ctx, char* buf, int cap) {

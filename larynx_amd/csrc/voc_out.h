@@ -163,6 +163,8 @@ __global__ __launch_bounds__(256) void post_conv_kernel(const PostArgs a) {
   }
 }
 
+constexpr int VOC_MAX_ROWS = 16;  // rows of a call with per-row destinations
+
 struct WaveOutArgs {
   const float* wav;  // [B][bs] finished float rows
   long long bs;
@@ -178,6 +180,13 @@ struct WaveOutArgs {
   short* i16;  // optional: same layout
   long long i_bs, i_ld;
   int pad_before;
+  // per_row != 0: the rows of a coalesced call (host_join.h) go to different callers — row b's float / int16 destination, row
+  // length and pause come from the tables below instead of base + b * stride (a null entry = that row has no such output)
+  int per_row;
+  float* f32_rows[VOC_MAX_ROWS];
+  short* i16_rows[VOC_MAX_ROWS];
+  long long f_ld_rows[VOC_MAX_ROWS], i_ld_rows[VOC_MAX_ROWS];
+  int pad_rows[VOC_MAX_ROWS];
 };
 
 __global__ __launch_bounds__(256) void wave_out_kernel(const WaveOutArgs a) {
@@ -185,14 +194,18 @@ __global__ __launch_bounds__(256) void wave_out_kernel(const WaveOutArgs a) {
   const long long N = (long long)a.frames[b] * a.hop;
   const float* src = a.wav + (long long)b * a.bs;
   const long long step = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.f32) {
-    float* dst = a.f32 + (long long)b * a.f_bs;
-    for (long long i = first; i < a.f_ld; i += step) {
-      const long long j = i - a.pad_before;
+  const int pad_before = a.per_row ? a.pad_rows[b] : a.pad_before;
+  float* const f32 = a.per_row ? a.f32_rows[b] : (a.f32 ? a.f32 + (long long)b * a.f_bs : nullptr);
+  short* const i16 = a.per_row ? a.i16_rows[b] : (a.i16 ? a.i16 + (long long)b * a.i_bs : nullptr);
+  if (f32) {
+    float* dst = f32;
+    const long long f_ld = a.per_row ? a.f_ld_rows[b] : a.f_ld;
+    for (long long i = first; i < f_ld; i += step) {
+      const long long j = i - pad_before;
       dst[i] = (j >= 0 && j < N) ? src[j] : 0.f;
     }
   }
-  if (a.i16) {
+  if (i16) {  // (uniform per workgroup: the barrier below is safe)
     __shared__ float pm[4];
     const int np = a.peak_parts ? a.peak_parts : (int)((N + POST_TW - 1) / POST_TW);
     float m = 0.f;
@@ -203,10 +216,11 @@ __global__ __launch_bounds__(256) void wave_out_kernel(const WaveOutArgs a) {
     __syncthreads();
     const float peak = fmaxf(0.01f, fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
     const float g = 32767.0f / peak;
-    short* dst = a.i16 + (long long)b * a.i_bs;
-    for (long long i = first; i < a.i_ld; i += step) {
+    short* dst = i16;
+    const long long i_ld = a.per_row ? a.i_ld_rows[b] : a.i_ld;
+    for (long long i = first; i < i_ld; i += step) {
       short s = 0;
-      const long long j = i - a.pad_before;
+      const long long j = i - pad_before;
       if (j >= 0 && j < N) {
         float v = src[j] * g;
         v = fminf(fmaxf(v, -32767.0f), 32767.0f);

@@ -450,11 +450,21 @@ class Engine:
         ffi.check(self.lib, self.lib.mi355tts_profile_json(self._ctx, buf, 4096))
         return json.loads(buf.value.decode("ascii"))
 
+    def get_call_coalesce_default(self) -> int:
+        """The library's built-in default of option `call_coalesce` (`mi355tts_call_coalesce_default`)."""
+        return int(self.lib.mi355tts_call_coalesce_default())
+
+    def profile_kernels(self) -> dict:
+        """The profiled launches per kernel NAME and sub-key (`mi355tts_profile_kernels_json`): {class: {"name/sub": {...}}}."""
+        buf = C.create_string_buffer(32768)
+        ffi.check(self.lib, self.lib.mi355tts_profile_kernels_json(self._ctx, buf, 32768))
+        return json.loads(buf.value.decode("ascii"))
+
     def dispatch_selfcheck(self) -> dict:
         """The one-off check of the dispatch-order assumption (`mi355tts_dispatch_selfcheck`): runs it if it has not run."""
         st, a, b = C.c_int(0), C.c_float(0.0), C.c_float(0.0)
         ffi.check(self.lib, self.lib.mi355tts_dispatch_selfcheck(self._ctx, C.byref(st), C.byref(a), C.byref(b)))
-        return {"state": {0: "not run", 1: "snake order kept", 2: "snake order and promotion switched off", 3: "skipped"}[int(st.value)],
+        return {"state": {0: "not run", 1: "snake order kept", 2: "snake order switched off", 3: "skipped", 4: "running"}[int(st.value)],
                 "plain_us": float(a.value), "snake_us": float(b.value)}
 
     def kernel_counts(self) -> dict:

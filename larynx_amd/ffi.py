@@ -146,6 +146,8 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
     "mi355tts_coalesce_stats": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi355tts_profile_reset": (C.c_int, [_VP]),
     "mi355tts_profile_json": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "mi355tts_call_coalesce_default": (C.c_int, []),
+    "mi355tts_profile_kernels_json": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "mi355tts_kernel_counts_json": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "mi355tts_dispatch_selfcheck": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mi355tts_profile_event_overhead": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double)]),

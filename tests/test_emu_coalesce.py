@@ -1,6 +1,8 @@
-"""Coalesced GlowTTS passes (csrc/host_join.h, option `glow_coalesce`) on the CPU emulator build: concurrent batch-1
-`mi355tts_synthesize` calls — the reference's per-sentence thread pool (larynx/__init__.py:146-157, 187-190) — share GlowTTS
-passes, and every caller still gets exactly the waveform of its own solitary call (same noise stream, same launches)."""
+"""Whole-call coalescing (csrc/host_join.h, option `call_coalesce`) on the CPU emulator build: concurrent batch-1
+`mi355tts_synthesize` calls — the reference's per-sentence thread pool (larynx/__init__.py:146-157, 187-190) — become the rows
+of fused padded calls (acoustic pass AND vocoder), each row with its own seed's noise stream, its own pause padding and its own
+output buffers.  A row equals its solitary call up to f32 summation order (a padded batch picks other tiles): frames
+identical, float waveform RMS <= 1e-5, int16 within 1 LSB."""
 import threading
 
 import numpy as np
@@ -16,12 +18,11 @@ from larynx_amd.ffi import Mi355ttsError
 def tiny(emu_engine):
     gsd = synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=7)
     vsd = synthetic.make_hifigan_state_dict(HP.TINY_HIFIGAN, seed=7)
-    emu_engine.set_option("glow_coalesce", 1)  # off by default
     yield dict(g=emu_engine.load_glow(HP.TINY_GLOW, gsd), v=emu_engine.load_hifigan(HP.TINY_HIFIGAN, vsd))
-    emu_engine.set_option("glow_coalesce", 0)
+    emu_engine.set_option("call_coalesce", 0)
 
 
-def _concurrent(eng, fn, n):
+def _concurrent(fn, n):
     out, err = [None] * n, [None] * n
     bar = threading.Barrier(n)
 
@@ -40,26 +41,51 @@ def _concurrent(eng, fn, n):
     return out, err
 
 
-def test_concurrent_calls_share_passes_and_equal_their_solitary_results(emu_engine, tiny):
+def assert_row_equals_solitary(solo, row):
+    (fa, wa, ia), (fb, wb, ib) = solo, row
+    assert np.array_equal(fa, fb)
+    assert ia.shape == ib.shape
+    assert np.abs(ia.astype(np.int32) - ib.astype(np.int32)).max() <= 1
+    if wa is not None:
+        assert np.sqrt(np.mean((wa - wb) ** 2)) <= 1e-5
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_concurrent_calls_ride_fused_passes_and_equal_their_solitary_results(emu_engine, tiny, lanes):
     eng, g, v = emu_engine, tiny["g"], tiny["v"]
     s = ljspeech_audio_settings()
     rng = np.random.default_rng(5)
     lens = (13, 7, 21, 9, 30, 17)
+    pads = ((0, 0), (5, 9), (0, 3), (11, 0), (2, 2), (0, 0))  # every row its own SSML pauses (larynx/__init__.py:277-283)
     ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols) for n in lens]
-    eng.set_option("glow_coalesce", 0)
+
+    def call(i):
+        return eng.synthesize(g, v, ids[i], 0.667, 1.0, seed=100 + i, audio_settings=s, want_float=True, pad_before=pads[i][0],
+                              pad_after=pads[i][1])
+
+    eng.set_option("call_coalesce", 0)
+    solo = [call(i) for i in range(len(ids))]
+    eng.set_option("call_coalesce", lanes)
+    eng.set_option("call_coalesce_window_us", 20000)  # emulator kernels take milliseconds: a wide gather window
     try:
-        solo = [eng.synthesize(g, v, ids[i], 0.667, 1.0, seed=100 + i, audio_settings=s, want_float=True) for i in range(len(ids))]
+        p0, r0 = eng.coalesce_stats()
+        out, err = _concurrent(call, len(ids))
+        assert not any(err), err
+        p1, r1 = eng.coalesce_stats()
+        assert r1 - r0 == len(ids)
+        assert p1 - p0 < len(ids)  # the callers that arrived while the first pass ran shared the next one(s)
+        hop = eng.hop(v)
+        for i, (a, b) in enumerate(zip(solo, out)):
+            assert_row_equals_solitary(a, b)
+            n = int(b[0][0]) * hop
+            assert np.all(b[2][0, : pads[i][0]] == 0) and np.all(b[2][0, pads[i][0] + n :] == 0)
+            assert np.all(b[1][0, : pads[i][0]] == 0) and np.all(b[1][0, pads[i][0] + n :] == 0)
+        # a lone caller: nothing to share, no gather window — and the SAME BITS as with the option off (same tiles, same launches)
+        lone = call(2)
+        assert np.array_equal(lone[2], solo[2][2]) and np.array_equal(lone[1], solo[2][1])
     finally:
-        eng.set_option("glow_coalesce", 1)
-    p0, r0 = eng.coalesce_stats()
-    out, err = _concurrent(eng, lambda i: eng.synthesize(g, v, ids[i], 0.667, 1.0, seed=100 + i, audio_settings=s, want_float=True), len(ids))
-    assert not any(err), err
-    p1, r1 = eng.coalesce_stats()
-    assert r1 - r0 == len(ids)
-    assert p1 - p0 < len(ids)  # the callers that arrived while the first pass ran shared the next one(s)
-    for (fa, wa, ia), (fb, wb, ib) in zip(solo, out):
-        assert np.array_equal(fa, fb)
-        assert np.array_equal(ia, ib) and np.array_equal(wa, wb)  # noise on: each row drew from its OWN seed's stream
+        eng.set_option("call_coalesce", 0)
+        eng.set_option("call_coalesce_window_us", 300)
 
 
 def test_incompatible_requests_do_not_share_a_pass(emu_engine, tiny):
@@ -69,18 +95,19 @@ def test_incompatible_requests_do_not_share_a_pass(emu_engine, tiny):
     rng = np.random.default_rng(6)
     ids = [synthetic.synthetic_phoneme_ids(rng, 12, HP.TINY_GLOW.num_symbols) for _ in range(4)]
     scales = (1.0, 1.3, 1.0, 1.3)
-    eng.set_option("glow_coalesce", 0)
+    eng.set_option("call_coalesce", 0)
+    solo = [eng.synthesize(g, v, ids[i], 0.5, scales[i], seed=7 + i, audio_settings=s) for i in range(4)]
+    eng.set_option("call_coalesce", 2)
     try:
-        solo = [eng.synthesize(g, v, ids[i], 0.5, scales[i], seed=7 + i, audio_settings=s) for i in range(4)]
+        out, err = _concurrent(lambda i: eng.synthesize(g, v, ids[i], 0.5, scales[i], seed=7 + i, audio_settings=s), 4)
     finally:
-        eng.set_option("glow_coalesce", 1)
-    out, err = _concurrent(eng, lambda i: eng.synthesize(g, v, ids[i], 0.5, scales[i], seed=7 + i, audio_settings=s), 4)
+        eng.set_option("call_coalesce", 0)
     assert not any(err), err
-    for (fa, _, ia), (fb, _, ib) in zip(solo, out):
-        assert np.array_equal(fa, fb) and np.array_equal(ia, ib)
+    for a, b in zip(solo, out):
+        assert_row_equals_solitary(a, b)
 
 
-def test_an_invalid_request_fails_alone_when_it_leads_and_with_its_pass_otherwise(emu_engine, tiny):
+def test_an_invalid_request_fails_alone(emu_engine, tiny):
     """An out-of-range phoneme id is caught by the caller's own pre-check, before it can join a pass."""
     eng, g, v = emu_engine, tiny["g"], tiny["v"]
     s = ljspeech_audio_settings()
@@ -88,6 +115,34 @@ def test_an_invalid_request_fails_alone_when_it_leads_and_with_its_pass_otherwis
     good = synthetic.synthetic_phoneme_ids(rng, 10, HP.TINY_GLOW.num_symbols)
     bad = good.copy()
     bad[3] = HP.TINY_GLOW.num_symbols + 5
-    out, err = _concurrent(eng, lambda i: eng.synthesize(g, v, bad if i == 1 else good, 0.667, 1.0, seed=3, audio_settings=s), 3)
+    eng.set_option("call_coalesce", 2)
+    try:
+        out, err = _concurrent(lambda i: eng.synthesize(g, v, bad if i == 1 else good, 0.667, 1.0, seed=3, audio_settings=s), 3)
+    finally:
+        eng.set_option("call_coalesce", 0)
     assert isinstance(err[1], Mi355ttsError) and err[0] is None and err[2] is None
-    assert np.array_equal(out[0][2], out[2][2])
+    assert np.abs(out[0][2].astype(np.int32) - out[2][2].astype(np.int32)).max() <= 1
+
+
+def test_a_row_whose_buffer_is_too_small_fails_alone_and_reports_its_frames(emu_engine, tiny):
+    """One rider's output buffer is too small for ITS frame count: the shared pass is abandoned, every rider runs its solitary
+    call — the others succeed, the small one gets MI355TTS_ERR_TOO_SMALL with the real frame count (the engine then retries with
+    the exact size, as it does for a solitary call)."""
+    eng, g, v = emu_engine, tiny["g"], tiny["v"]
+    s = ljspeech_audio_settings()
+    rng = np.random.default_rng(9)
+    ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.TINY_GLOW.num_symbols) for n in (14, 16, 12)]
+    eng.set_option("call_coalesce", 0)
+    solo = [eng.synthesize(g, v, ids[i], 0.667, 1.0, seed=40 + i, audio_settings=s) for i in range(3)]
+    eng.set_option("call_coalesce", 1)
+    eng.set_option("call_coalesce_window_us", 20000)
+    try:
+        # row 1's first attempt is sized for 0.2 frames per id: far too small; Engine.synthesize repeats it with the exact size
+        out, err = _concurrent(lambda i: eng.synthesize(g, v, ids[i], 0.667, 1.0, seed=40 + i, audio_settings=s,
+                                                       frames_per_id_guess=0.2 if i == 1 else 8.0), 3)
+    finally:
+        eng.set_option("call_coalesce", 0)
+        eng.set_option("call_coalesce_window_us", 300)
+    assert not any(err), err
+    for a, b in zip(solo, out):
+        assert_row_equals_solitary(a, b)

@@ -39,17 +39,6 @@ def check_synthesize_equals_two_calls(eng, g, v, num_symbols, hop, lens=(13, 7, 
         for b in range(len(frames)):
             n = int(frames[b]) * hop
             assert np.array_equal(i1[b, 5 : 5 + n], i0[b, :n])
-    # option "glow_priority": the acoustic pass on a priority stream of the call's worker, the vocoder behind an event — same bits
-    eng.set_option("glow_priority", 1)
-    try:
-        for ids in (rows[0], rows):
-            ref = eng.synthesize(g, v, ids, 0.667, 1.0, seed=99, audio_settings=s, want_float=True)
-            eng.set_option("glow_priority", 0)
-            off = eng.synthesize(g, v, ids, 0.667, 1.0, seed=99, audio_settings=s, want_float=True)
-            eng.set_option("glow_priority", 1)
-            assert all(np.array_equal(a, b) for a, b in zip(ref, off))
-    finally:
-        eng.set_option("glow_priority", 0)
     # a guess that is too small is retried with a bigger buffer
     frames, _, i3 = eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9, frames_per_id_guess=0.2)
     assert np.array_equal(i3, eng.synthesize(g, v, rows[0], 0.667, 1.0, seed=99, audio_settings=s, pad_before=5, pad_after=9)[2])
@@ -240,6 +229,39 @@ def test_fresh_seed_per_call_by_default(emu_library, tmp_path):
     assert a.shape == b.shape and not np.array_equal(a, b)
     c, d = np.asarray(tts.phonemes_to_mels(ids, {"seed": 5})), np.asarray(tts.phonemes_to_mels(ids, {"seed": 5}))
     assert np.array_equal(c, d)
+
+
+def check_seeded_path_equals_injected_noise(eng, g, num_symbols, channels, lens=(120,), seed=4321, length_scale=0.65):
+    """The TIMED noise mode against the PARITY-CHECKED one (both stand in for glow_tts/models.py:348, `torch.randn_like`):
+    `glow_infer(seed = s)` — the generator fused into expand_noise_squeeze_kernel, row b on the stream s + b — must be, bit for
+    bit, `glow_infer(noise = gauss_noise(s, B, M, T))`, the same field generated by itself and injected like a golden's recorded
+    noise.  An indexing slip between the generator and its fused consumer (channel / frame / row keys) would pass the
+    distribution test and fail here."""
+    rng = np.random.default_rng(seed)
+    rows = [synthetic.synthetic_phoneme_ids(rng, n, num_symbols) for n in lens]
+    x = rows[0] if len(rows) == 1 else rows
+    seeded = eng.glow_infer(g, x, 0.667, length_scale, seed=seed)
+    frames = [int(f) for f in seeded.frames]
+    T = max(frames) + 7  # (a wider field than needed: the row stride of the injected noise is not the frame count)
+    field = eng.gauss_noise(seed, len(rows), channels, T)
+    injected = eng.glow_infer(g, x, 0.667, length_scale, noise=field)
+    try:
+        assert [int(f) for f in injected.frames] == frames and min(frames) > 0
+        a, b = seeded.numpy("raw"), injected.numpy("raw")
+        assert np.array_equal(a, b)
+        # and the noise is really there: another seed gives another mel
+        other = eng.glow_infer(g, x, 0.667, length_scale, seed=seed + 1000)
+        assert [int(f) for f in other.frames] == frames and not np.array_equal(other.numpy("raw"), a)
+        other.free()
+    finally:
+        seeded.free()
+        injected.free()
+
+
+def test_seeded_path_equals_injected_noise(emu_engine, tiny):
+    hp = HP.TINY_GLOW
+    check_seeded_path_equals_injected_noise(emu_engine, tiny["g"], hp.num_symbols, hp.mel_channels, lens=(23,), length_scale=1.0)
+    check_seeded_path_equals_injected_noise(emu_engine, tiny["g"], hp.num_symbols, hp.mel_channels, lens=(17, 5, 30), length_scale=1.0)
 
 
 def test_device_noise_is_standard_normal(emu_engine):

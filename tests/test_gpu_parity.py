@@ -284,9 +284,10 @@ def test_threads_share_one_engine(gpu_engine):
 
 
 def test_coalesced_calls_equal_their_solitary_results(gpu_engine):
-    """csrc/host_join.h on the device: eight threads' batch-1 fused calls (ragged lengths on both sides of the 16- and
-    32-column tile seams, the device RNG on) share GlowTTS passes, and every caller gets the bits of its solitary call —
-    its own seed's noise stream, the launches of a batch-1 call — in f32 and in the split-bf16 mode."""
+    """csrc/host_join.h on the device (option `call_coalesce`): eight threads' batch-1 fused calls (ragged lengths on both sides
+    of the 16- and 32-column tile seams, the device RNG on, a pause before / after some rows, device AND host outputs) ride fused
+    padded calls, and every caller gets its solitary call's result to f32 round-off — frames identical, float waveform RMS <=
+    1e-5, int16 within 1 LSB — in f32 and in the split-bf16 mode; a lone caller gets the same BITS as with the option off."""
     import threading
 
     from larynx_amd import ffi
@@ -295,35 +296,57 @@ def test_coalesced_calls_equal_their_solitary_results(gpu_engine):
     s = ljspeech_audio_settings()
     rng = np.random.default_rng(77)
     lens = (120, 33, 64, 97, 120, 15, 81, 50)
+    pads = ((0, 0), (220, 0), (0, 441), (0, 0), (100, 100), (0, 0), (0, 0), (7, 3))
     ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in lens]
+
+    def call(i):
+        return gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True, pad_before=pads[i][0],
+                                     pad_after=pads[i][1])
+
     for precision in (ffi.PRECISION_F32, ffi.PRECISION_BF16X3):
         gpu_engine.set_precision(v, precision)
         try:
-            gpu_engine.set_option("glow_coalesce", 0)
-            solo = [gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True) for i in range(len(ids))]
-            gpu_engine.set_option("glow_coalesce", 1)
-            p0, r0 = gpu_engine.coalesce_stats()
-            for rep in range(3):
-                out = [None] * len(ids)
-                bar = threading.Barrier(len(ids))
+            gpu_engine.set_option("call_coalesce", 0)
+            solo = [call(i) for i in range(len(ids))]
+            for lanes in (1, 2, 3):
+                gpu_engine.set_option("call_coalesce", lanes)
+                p0, r0 = gpu_engine.coalesce_stats()
+                for rep in range(3):
+                    out = [None] * len(ids)
+                    bar = threading.Barrier(len(ids))
 
-                def work(i):
-                    bar.wait()
-                    out[i] = gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True)
+                    def work(i):
+                        bar.wait()
+                        out[i] = call(i)
 
-                th = [threading.Thread(target=work, args=(i,)) for i in range(len(ids))]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                for (fa, wa, ia), (fb, wb, ib) in zip(solo, out):
-                    assert np.array_equal(fa, fb)
-                    assert np.array_equal(wa, wb) and np.array_equal(ia, ib)
-            p1, r1 = gpu_engine.coalesce_stats()
-            assert r1 - r0 >= 3 * len(ids) and p1 - p0 < r1 - r0, (p1 - p0, r1 - r0)  # passes were shared
+                    th = [threading.Thread(target=work, args=(i,)) for i in range(len(ids))]
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    for (fa, wa, ia), (fb, wb, ib) in zip(solo, out):
+                        assert np.array_equal(fa, fb) and ia.shape == ib.shape
+                        assert np.abs(ia.astype(np.int32) - ib.astype(np.int32)).max() <= 1
+                        assert np.sqrt(np.mean((wa - wb) ** 2)) <= 1e-5
+                p1, r1 = gpu_engine.coalesce_stats()
+                assert r1 - r0 == 3 * len(ids) and p1 - p0 < r1 - r0, (p1 - p0, r1 - r0)  # passes were shared
+                lone = call(3)
+                assert np.array_equal(lone[1], solo[3][1]) and np.array_equal(lone[2], solo[3][2])
         finally:
-            gpu_engine.set_option("glow_coalesce", 0)
+            gpu_engine.set_option("call_coalesce", gpu_engine.get_call_coalesce_default())
             gpu_engine.set_precision(v, ffi.PRECISION_F32)
+
+
+def test_seeded_path_equals_injected_noise(gpu_engine):
+    """`glow_infer(seed = s)` (what bench.py times) == `glow_infer(noise = gauss_noise(s, ...))` (how every parity test feeds the
+    reference's recorded `randn_like` draw, glow_tts/models.py:348), bit for bit at ljspeech size: batch 1 and a ragged batch
+    of 3 (row b draws the stream s + b)."""
+    from tests.test_emu_host_features import check_seeded_path_equals_injected_noise
+
+    (gsd, g), _ = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    hp = HP.LJSPEECH
+    check_seeded_path_equals_injected_noise(gpu_engine, g, hp.num_symbols, hp.mel_channels, lens=(120,))
+    check_seeded_path_equals_injected_noise(gpu_engine, g, hp.num_symbols, hp.mel_channels, lens=(120, 47, 90), seed=99)
 
 
 def test_glowtts_launch_counts_on_the_device(gpu_engine):
@@ -344,7 +367,7 @@ def test_glowtts_launch_counts_on_the_device(gpu_engine):
     hp = HP.LJSPEECH
     # by kernel name: the 16-row gate tile, the block tails and conv_o + LayerNorm as column owners; no generic-tile fallback
     assert names["gate16_kernel"] == hp.n_blocks_dec * hp.n_block_layers and names["glow_tail_kernel"] == hp.n_blocks_dec
-    assert names["oproj_ln_kernel"] == hp.n_layers_enc and names["wn_layer_kernel"] == 0
+    assert names["oproj_ln_kernel"] == hp.n_layers_enc
     assert names["lin16_kernel"] + names["lin16_kernel.ln"] >= hp.n_blocks_dec * (hp.n_block_layers - 1) + 2 * hp.n_layers_enc
     assert prof["conv_mfma.glow_decoder"]["launches"] == 1 + hp.n_blocks_dec * (2 * hp.n_block_layers)
     assert prof["conv_mfma.glow_encoder"]["launches"] == 4 + hp.n_layers_enc * 4 + 3
@@ -362,43 +385,6 @@ VOC_KERNELS = {
     "medium": {"pair_group_kernel": 6, "rb_pair_group_kernel": 0, "rb_group_kernel": 0, "rb_group_kernel.snake": 0, "conv_group_kernel": 0,
                "mrf_small_kernel": 1, "mrf8_kernel": 1},
 }
-
-
-def test_wavenet_layer_column_owner_form_computes_the_same_bits(gpu_engine):
-    """csrc/wn_layer.h (option `wn_layer`; off by default: profiles/r05_wn_layer_ab.txt): one column-owner launch per WaveNet
-    layer promises the SAME BITS as gate16_kernel + lin16_kernel on the real matrix pipes — the standard utterance with the
-    device's noise.  In a big padded batch the launches it replaces are other tiles (the res_skip convs take the 64-row tile
-    there: run_lin16), so the bar for the ragged batch of eight is f32 round-off: against the other form and against every row's
-    own batch-1 call."""
-    (gsd, g), _ = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
-    rng = np.random.default_rng(11)
-    one = synthetic.synthetic_phoneme_ids(rng, 120, HP.LJSPEECH.num_symbols)
-    rows = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in (19, 26, 31, 33, 64, 47, 90, 120)]
-    hp = HP.LJSPEECH
-
-    def run(x, form, **kw):
-        gpu_engine.set_option("wn_layer", form)
-        try:
-            gpu_engine.profile_reset()
-            mel = gpu_engine.glow_infer(g, x, 0.667, 0.65, **kw)
-            out = (mel.numpy("raw").copy(), [int(f) for f in mel.frames], gpu_engine.kernel_counts())
-            mel.free()
-            return out
-        finally:
-            gpu_engine.set_option("wn_layer", 0)
-
-    on, off = run(one, 2, seed=5), run(one, 0, seed=5)
-    assert on[2]["wn_layer_kernel"] == hp.n_blocks_dec * (hp.n_block_layers - 1) and on[2]["gate16_kernel"] == 0
-    assert on[2]["wn_layer_kernel.gate_only"] == hp.n_blocks_dec
-    assert off[2]["wn_layer_kernel"] == 0 and off[2]["gate16_kernel"] == hp.n_blocks_dec * hp.n_block_layers
-    assert on[1] == off[1] and np.array_equal(on[0], off[0])
-    bon, boff = run(rows, 2, seed=20), run(rows, 0, seed=20)
-    assert bon[2]["wn_layer_kernel"] == hp.n_blocks_dec * (hp.n_block_layers - 1) and bon[1] == boff[1]
-    assert np.abs(bon[0] - boff[0]).max() <= 2e-5
-    for r, ids in enumerate(rows):  # (a padded batch picks other tiles for the encoder and the start conv than a batch-1 call)
-        solo = run(ids, 2, seed=20 + r)
-        assert solo[1][0] == bon[1][r]
-        assert np.abs(solo[0][0][:, : solo[1][0]] - bon[0][r][:, : bon[1][r]]).max() <= 2e-5
 
 
 @pytest.mark.parametrize("quality,resblock,narrow", [("high", 18, 0), ("medium", 6, 2)])

@@ -121,12 +121,17 @@ def test_glow_small_launch_kernels(resources):
 
 
 def test_round5_kernels(resources):
-    """wn_layer_kernel (wn_layer.h): four waves per SIMD by registers (<= 128, no scratch) and under 32 KB of LDS — the hole one
-    finishing ResBlock workgroup leaves; post_conv_kernel (voc_out.h): no scratch, three workgroups per CU."""
-    wn = {n: r for n, r in resources.items() if "wn_layer_kernel" in n}
-    assert len(wn) == 4, sorted(wn)  # k = 5 / 3, with / without the res_skip phase
-    for n, r in wn.items():
-        assert r["scratch"] == 0 and r["vgprs"] <= 128 and r["lds"] <= 32 * 1024 and r["occupancy"] >= 4, (n, r)
+    """post_conv_kernel (voc_out.h): no scratch, three workgroups per CU; the attention instantiations.  (The column-owner
+    WaveNet layer of round 5 is no longer in the product library: tools/probe/wn_layer.h.)"""
+    assert not [n for n in resources if "wn_layer_kernel" in n]
+    # lin16_kernel: two workgroups per CU for every form (<= 80 KB; the Cin = 768 FFN conv is the largest at 72 KB), and the
+    # wide-pass form (four row tiles per workgroup), whose reduction scratch sets its size, at exactly 64 KB
+    lin = {n: r for n, r in resources.items() if "lin16_kernel" in n}
+    assert len(lin) >= 9, sorted(lin)
+    for n, r in lin.items():
+        assert r["scratch"] == 0 and r["lds"] <= 80 * 1024, (n, r)
+    wide = [r for n, r in lin.items() if n.endswith("Lb0ELi4EEEvNS_9Lin16ArgsE")]
+    assert len(wide) == 1 and wide[0]["lds"] <= 66 * 1024, sorted(lin)
     post = {n: r for n, r in resources.items() if "post_conv_kernel" in n}
     assert len(post) == 3, sorted(post)
     for n, r in post.items():

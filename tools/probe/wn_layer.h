@@ -2,7 +2,9 @@
 // (glow_tts/layers.py:138-162 — x_in = in_layers[i](x) [+ g_l]; acts = tanh(x_in[:H]) * sigmoid(x_in[H:])
 // (glow_tts/utils.py:31-38); res_skip = res_skip_layers[i](acts); x = (x + res_skip[:H]) * mask; output += res_skip[H:]).
 //
-// STATUS: measured and NOT in the default path (option "wn_layer" = 0).  The form was built on the reading that, next to other
+// STATUS (round 6): NOT part of the product library any more — an experiment record.  It was compiled into libmi355tts.so
+// behind option "wn_layer" (default 0) in round 5 (commit 4c32bea and before: csrc/wn_layer.h, the dispatch in glow_forward.h /
+// host_launch.h, tests/test_emu_wn_layer.py), measured slower under every load and taken out; nothing includes this file.  The form was built on the reading that, next to other
 // calls, a GlowTTS launch costs the CU residency it takes from the vocoder's ResBlock workgroups, not its latency (VERDICT
 // r04): gate16.h / lin16_kernel run this layer as 240 + 120 workgroups of 512 threads that each stage a [H x 40] tile, run
 // 30-60 MFMAs per wave and meet in LDS (8 + 5 us on an idle chip at 3-10 % of the matrix pipes); here a workgroup OWNS 16 time
