@@ -673,6 +673,7 @@ def main():
     # the same region with the other setting of option "call_coalesce" (csrc/host_join.h: concurrent batch-1 callers become the
     # rows of fused padded calls), reported next to the headline — which runs the library's DEFAULT
     t_flight_nc = t_flight
+    t_steady_nc = None
     cs0 = cs1 = (0, 0)
     cc_default = eng.get_call_coalesce_default()
     cc_other = 0 if cc_default else args.call_coalesce_lanes
@@ -682,6 +683,25 @@ def main():
         cs0 = eng.coalesce_stats()
         t_flight_nc = timed(lambda: run_steps(W, n_utts), max(3, repeats // 3))
         cs1 = eng.coalesce_stats()
+        if not args.tiny and not args.no_steady_state:  # and one steady-state region (10 x K steps) with that setting
+            import queue as _q
+
+            def run_long_cc():
+                q = _q.SimpleQueue()
+                for j in range(10 * K):
+                    q.put(W + (j % K))
+
+                def work(slot):
+                    while True:
+                        try:
+                            i = q.get_nowait()
+                        except _q.Empty:
+                            return
+                        step(i, slot)
+
+                list(pool.map(work, range(conc)))
+
+            t_steady_nc = timed(run_long_cc, 2)
         eng.set_option("call_coalesce", cc_default)
         run_steps(0, max(W, conc))
     t_dn = timed(lambda: run_steps(W, n_utts, denoiser=0.005), max(3, repeats // 3)) if dn_ok else [float("nan")]
@@ -1054,6 +1074,7 @@ def main():
                 "rows_per_pass": (cs1[1] - cs0[1]) / max(1, cs1[0] - cs0[0]),
                 "utterances_per_sec": world * K * B / dt_flight_nc,
                 "ms_per_step": 1e3 * dt_flight_nc / K,
+                "steady_state_utterances_per_sec_rank0": None if not t_steady_nc else 10 * K * B / float(np.median(t_steady_nc)),
             },
             "denoiser_on": None if not dn_ok else {
                 "denoiser_strength": 0.005,

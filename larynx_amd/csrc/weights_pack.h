@@ -105,6 +105,54 @@ inline PackedConv16 pack_conv_bf16(int rows, int m_align, int Cin, int K, WGet w
   return p;
 }
 
+// ---- fp16 fragments for conv_f16.h (the native 16-bit mode) ---------------------------------------
+inline uint16_t f16_rne(float v) {
+  const _Float16 h = (_Float16)v;  // round to nearest even; overflow -> inf (weights of a sane checkpoint are far from 65504)
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+inline float f16_to_float(uint16_t u) {
+  _Float16 h;
+  std::memcpy(&h, &u, 2);
+  return (float)h;
+}
+struct PackedConvH {
+  std::vector<uint16_t> w;  // [mtiles][nslab][K][64 lanes][8]
+  std::vector<float> bias;  // [mtiles * 32] f32, virtual-row order
+  int mtiles = 0, nslab = 0, K = 0, rows = 0;
+};
+// lane l of (m-tile, 16-channel slab, tap) holds the weights of virtual row 32 mt + (l & 31), channels 16 slab + 8 (l >> 5) .. + 7:
+// the A operand of one v_mfma_f32_32x32x16_f16.  Rows padded to whole `m_align` tiles, channels to whole `ch_align`-channel
+// chunks, with zeros.  `wget(v, ci, k)` reads the logical weight of VIRTUAL row v, `bget(v)` its bias.
+template <typename WGet, typename BGet>
+inline PackedConvH pack_conv_f16(int rows, int m_align, int Cin, int K, int ch_align, WGet wget, BGet bget, bool has_bias) {
+  PackedConvH p;
+  int mt = (rows + 31) / 32;
+  mt = ((mt + m_align - 1) / m_align) * m_align;
+  p.mtiles = mt;
+  p.nslab = (ch_align / 16) * ((Cin + ch_align - 1) / ch_align);
+  p.K = K;
+  p.rows = rows;
+  p.w.assign((size_t)mt * p.nslab * K * 64 * 8, 0);
+  p.bias.assign((size_t)mt * 32, 0.f);
+  for (int m = 0; m < mt; ++m)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int v = m * 32 + (lane & 31);
+      if (v >= rows) continue;
+      if (has_bias && lane < 32) p.bias[v] = bget(v);
+      for (int slab = 0; slab < p.nslab; ++slab)
+        for (int k = 0; k < K; ++k) {
+          uint16_t* dst = &p.w[((((size_t)m * p.nslab + slab) * K + k) * 64 + lane) * 8];
+          for (int i = 0; i < 8; ++i) {
+            const int ci = slab * 16 + 8 * (lane >> 5) + i;
+            dst[i] = ci < Cin ? f16_rne(wget(v, ci, k)) : 0;
+          }
+        }
+    }
+  return p;
+}
+
 // ---- A fragments for mrf_small.h (v_mfma_f32_16x16x4_f32) ---------------------------------------
 // One conv w[C][C][K] with C <= 16 as [tap][C/4][64 lanes]: lane l of (tap, channel quad q) holds
 // W[co = l & 15][ci = 4q + (l >> 4)][tap] — the A operand A[i = l & 15][k = l >> 4] of one MFMA — and

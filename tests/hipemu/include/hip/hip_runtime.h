@@ -235,6 +235,29 @@ inline f32x16 mfma_f32_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_f16: the same lane maps with IEEE half operands (products of two halves are exact in f32)
+typedef _Float16 f16x8_emu __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_f32_32x32x16_f16(f16x8_emu a, f16x8_emu b, f32x16 c) {
+  BlockCtx* cx = ctx();
+  Fiber* f = cx->cur;
+  WaveState& w = cx->waves[f->wave];
+  const int l = f->lane;
+  for (int i = 0; i < 8; ++i) {
+    w.Ab[(l & 31) * 16 + 8 * (l >> 5) + i] = (float)a[i];
+    w.Bb[(8 * (l >> 5) + i) * 32 + (l & 31)] = (float)b[i];
+  }
+  wave_barrier();
+  const int col = l & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) acc = std::fmaf(w.Ab[row * 16 + k], w.Bb[k * 32 + col], acc);
+    c[reg] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur()->tid)
@@ -267,6 +290,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_f32_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, cbsz, abid, blgp) hipemu::mfma_f32_4x4x1((a), (b), (c), (cbsz), (abid))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_f16((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 // lanes are fibers here: a wave's lock step (an LDS write another lane of the SAME wave then reads) needs a real rendezvous

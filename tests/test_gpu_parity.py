@@ -300,8 +300,9 @@ def test_coalesced_calls_equal_their_solitary_results(gpu_engine):
     ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in lens]
 
     def call(i):
+        # (a generous buffer guess: a row whose buffer is too small sends its whole pass to the solitary path — tested on the emulator)
         return gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=500 + i, audio_settings=s, want_float=True, pad_before=pads[i][0],
-                                     pad_after=pads[i][1])
+                                     pad_after=pads[i][1], frames_per_id_guess=20.0)
 
     for precision in (ffi.PRECISION_F32, ffi.PRECISION_BF16X3):
         gpu_engine.set_precision(v, precision)

@@ -1,0 +1,283 @@
+// Harness of conv_f16.h (the native 16-bit vocoder tile): one conv / upsampler launch on random data, checked against a CPU
+// reference in double (fp16-rounded operands), then timed.  NOT part of the product library.
+//   GPU:      hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe/f16_bench.hip -o build/f16_bench
+//   emulator: clang++ -x c++ -std=c++17 -O2 -Itests/hipemu/include tools/probe/f16_bench.hip tests/hipemu/hipemu_runtime.cpp -lpthread
+// usage: f16_bench <Cin> <Cout> <K> <dil> <L> <cfg> [iters] [up]     (up > 0: polyphase upsampler with K = 2 taps)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../larynx_amd/csrc/conv_f16.h"
+#include "../../larynx_amd/csrc/weights_pack.h"
+
+using namespace mi355tts;
+
+#define HC(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      std::printf("%s failed: %s\n", #x, hipGetErrorString(e_));                  \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+template <int K, int EPI, bool MRF>
+static void launch(int cfg, dim3& grid_out, const HConvArgs& a, int n_len, hipStream_t s, bool really) {
+  constexpr int HALO = K == 2 ? 4 : ConvHalo<K>::v;
+#define CFG(ID, MB, NB, WM, WN, CH)                                                                                          \
+  if (cfg == ID) {                                                                                                           \
+    grid_out = dim3((n_len + 32 * NB * WN - 1) / (32 * NB * WN), (a.rows + 32 * MB * WM - 1) / (32 * MB * WM), 1);            \
+    if (really) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, MB, NB, WM, WN, HALO, CH, EPI, MRF>), grid_out, dim3(64 * WM * WN), 0, s, a); \
+    return;                                                                                                                  \
+  }
+  CFG(0, 2, 2, 2, 2, 64)  // 128 rows x 128 columns, wave 64 x 64
+  CFG(1, 2, 4, 2, 2, 64)  // 128 x 256, wave 64 x 128
+  CFG(2, 2, 2, 1, 4, 64)  // 64 x 256
+  CFG(3, 1, 2, 1, 4, 32)  // 32 x 256
+  CFG(4, 2, 2, 2, 2, 32)
+  CFG(5, 2, 4, 1, 4, 64)  // 64 x 512
+  CFG(6, 1, 4, 1, 4, 32)  // 32 x 512
+#undef CFG
+  std::printf("unknown cfg %d\n", cfg);
+}
+
+// grouped launch of the three MRF members (K = 11, 7, 3), timing only: f16_bench Cin Cout 0 dil L cfg iters
+template <int MB, int NB, int WM, int WN, int CH>
+static void launch_group(const HConvGroupArgs& g, dim3 grid) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<11, 7, 3, MB, NB, WM, WN, ConvHalo<11>::v, ConvHalo<7>::v, ConvHalo<3>::v, CH>), grid,
+                     dim3(64 * WM * WN), 0, nullptr, g);
+}
+static int run_group(int C, int dil, int L, int cfg, int iters) {
+  const int Ks[3] = {11, 7, 3};
+  const int noct = C / 8, ld = L + 3;
+  uint4 *dx, *dy[3], *dw[3];
+  float* db;
+  HC(hipMalloc(&dx, (size_t)noct * ld * 16));
+  HC(hipMemset(dx, 0, (size_t)noct * ld * 16));
+  HC(hipMalloc(&db, 4 * 1024));
+  HC(hipMemset(db, 0, 4 * 1024));
+  HConvGroupArgs g;
+  std::memset(&g, 0, sizeof(g));
+  int MBr = 2, NBc = 2, WMr = 2, WNc = 2;
+  if (cfg == 1) NBc = 4;
+  if (cfg == 2) { WMr = 1; WNc = 4; }
+  if (cfg == 3) { MBr = 1; WMr = 1; WNc = 4; }
+  if (cfg == 5) { NBc = 4; WMr = 1; WNc = 4; }
+  if (cfg == 6) { MBr = 1; NBc = 4; WMr = 1; WNc = 4; }
+  const int tcols = 32 * NBc * WNc, trows = 32 * MBr * WMr;
+  int off = 0;
+  double flop = 0;
+  for (int m = 0; m < 3; ++m) {
+    const int K = Ks[m];
+    std::vector<uint16_t> w((size_t)((C + 31) / 32) * 4 * (C / 16 + 4) * K * 64 * 8, f16_rne(0.01f));
+    HC(hipMalloc(&dw[m], w.size() * 2));
+    HC(hipMemcpy(dw[m], w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    HC(hipMalloc(&dy[m], (size_t)noct * ld * 16));
+    HConvArgs& a = g.c[m];
+    a.x = dx; a.x_bs = (long long)noct * ld; a.x_ld = ld; a.in_const = L; a.w = dw[m]; a.bias = db;
+    a.nslab = 4 * ((C + 63) / 64); a.Cin = C; a.rows = C; a.dil = dil; a.pad = (K * dil - dil) / 2; a.in_slope = 0.1f; a.out_slope = 1.0f;
+    a.y = dy[m]; a.y_bs = (long long)noct * ld; a.y_ld = ld; a.res = dx; a.out_const = L; a.cout = C;
+    g.gx[m] = (L + tcols - 1) / tcols;
+    g.gy[m] = (C + trows - 1) / trows;
+    g.off[m] = off;
+    off += (g.gx[m] * g.gy[m] + 7) & ~7;
+    flop += 2.0 * C * C * K * (double)L;
+  }
+  g.off[3] = off;
+  const dim3 grid(off, 1, 1);
+  auto go = [&]() {
+    if (cfg == 0) launch_group<2, 2, 2, 2, 64>(g, grid);
+    else if (cfg == 1) launch_group<2, 4, 2, 2, 64>(g, grid);
+    else if (cfg == 2) launch_group<2, 2, 1, 4, 64>(g, grid);
+    else if (cfg == 3) launch_group<1, 2, 1, 4, 32>(g, grid);
+    else if (cfg == 4) launch_group<2, 2, 2, 2, 32>(g, grid);
+    else if (cfg == 5) launch_group<2, 4, 1, 4, 64>(g, grid);
+    else launch_group<1, 4, 1, 4, 32>(g, grid);
+  };
+  for (int i = 0; i < 3; ++i) go();
+  hipEvent_t e0, e1;
+  HC(hipEventCreate(&e0));
+  HC(hipEventCreate(&e1));
+  HC(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) go();
+  HC(hipEventRecord(e1, nullptr));
+  HC(hipEventSynchronize(e1));
+  float ms = 0;
+  HC(hipEventElapsedTime(&ms, e0, e1));
+  const double us = 1e3 * ms / iters;
+  std::printf("GROUP C %d dil %d L %d cfg %d (%d workgroups): %.2f us per launch, %.1f TFLOP/s (%.3f of 2500)\n", C, dil, L, cfg, off, us, flop / us * 1e-6,
+              flop / us * 1e-6 / 2500.0);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 7) {
+    std::printf("usage: f16_bench Cin Cout K dil L cfg [iters] [up]\n");
+    return 2;
+  }
+  const int Cin = std::atoi(argv[1]), Cout = std::atoi(argv[2]), K = std::atoi(argv[3]), dil = std::atoi(argv[4]), L = std::atoi(argv[5]);
+  const int cfg = std::atoi(argv[6]);
+  const int iters = argc > 7 ? std::atoi(argv[7]) : 20;
+  const int up = argc > 8 ? std::atoi(argv[8]) : 0;
+  const bool mrf = argc > 9 && std::atoi(argv[9]) != 0;
+  if (K == 0) return run_group(Cin, dil, L, cfg, iters);
+  uint32_t st = 12345u;
+  auto rnd = [&]() {
+    st = st * 1664525u + 1013904223u;
+    return ((st >> 8) * (1.0f / 16777216.0f)) * 2.0f - 1.0f;
+  };
+  const int noct = (Cin + 7) / 8, ld = L + 3;
+  const int npl = mrf ? 3 : 1;
+  std::vector<uint16_t> hx((size_t)npl * noct * ld * 8, 0);
+  std::vector<float> fx((size_t)npl * Cin * L);
+  for (int p = 0; p < npl; ++p)
+    for (int c = 0; c < Cin; ++c)
+      for (int t = 0; t < L; ++t) {
+        const uint16_t h = f16_rne(rnd() * 2.0f);
+        hx[(size_t)p * noct * ld * 8 + ((size_t)(c / 8) * ld + t) * 8 + (c % 8)] = h;
+        fx[((size_t)p * Cin + c) * L + t] = f16_to_float(h);
+      }
+  const int Kt = up ? 2 : K;
+  const int rows = up ? Cout * up : Cout;
+  // logical weights: conv w[Cout][Cin][K]; transposed conv wt[Cin][Cout][2 up]
+  std::vector<float> w((size_t)Cout * Cin * (up ? 2 * up : K)), bias(Cout);
+  const float sc = 1.0f / std::sqrt((float)Cin * Kt);
+  for (auto& v : w) v = f16_to_float(f16_rne(rnd() * sc));
+  for (auto& v : bias) v = rnd();
+  PackedConvH pk;
+  if (up) {
+    pk = pack_conv_f16(
+        rows, 4, Cin, 2, 64,
+        [&](int v, int ci, int k) {
+          const int r = v / Cout, co = v % Cout, m = 1 - k;
+          return w[((size_t)ci * Cout + co) * (2 * up) + m * up + r];
+        },
+        [&](int v) { return bias[v % Cout]; }, true);
+  } else {
+    pk = pack_conv_f16(
+        rows, 4, Cin, K, 64, [&](int v, int ci, int k) { return w[((size_t)v * Cin + ci) * K + k]; }, [&](int v) { return bias[v]; }, true);
+  }
+  const int Lout = up ? L * up : L;
+  const int yoct = Cout / 8, yld = Lout + 5;
+  std::vector<uint16_t> hres((size_t)yoct * yld * 8, 0);
+  for (auto& v : hres) v = f16_rne(rnd());
+  uint4 *dx, *dw, *dy, *dres;
+  float* db;
+  HC(hipMalloc(&dx, hx.size() * 2));
+  HC(hipMalloc(&dw, pk.w.size() * 2));
+  HC(hipMalloc(&db, pk.bias.size() * 4));
+  HC(hipMalloc(&dy, (size_t)yoct * yld * 16));
+  HC(hipMalloc(&dres, (size_t)yoct * yld * 16));
+  HC(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  HC(hipMemcpy(dw, pk.w.data(), pk.w.size() * 2, hipMemcpyHostToDevice));
+  HC(hipMemcpy(db, pk.bias.data(), pk.bias.size() * 4, hipMemcpyHostToDevice));
+  HC(hipMemcpy(dres, hres.data(), hres.size() * 2, hipMemcpyHostToDevice));
+  HC(hipMemset(dy, 0, (size_t)yoct * yld * 16));
+  HConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = dx;
+  if (mrf) {
+    a.x2 = dx + (size_t)noct * ld;
+    a.x3 = dx + (size_t)2 * noct * ld;
+  }
+  a.in_div = 3.0f;
+  a.x_bs = (long long)noct * ld;
+  a.x_ld = ld;
+  a.in_const = L;
+  a.w = dw;
+  a.bias = db;
+  a.nslab = pk.nslab;
+  a.Cin = Cin;
+  a.rows = rows;
+  a.dil = up ? 1 : dil;
+  a.pad = up ? 1 : (K * dil - dil) / 2;
+  a.in_slope = 0.1f;
+  a.out_slope = up ? 1.0f : 0.1f;
+  a.y = dy;
+  a.y_bs = (long long)yoct * yld;
+  a.y_ld = yld;
+  a.res = up ? nullptr : dres;
+  a.out_const = Lout;
+  a.up = up;
+  a.up_pad = up / 2;
+  a.cout = Cout;
+  const int n_len = up ? L + 1 : L;
+  dim3 grid;
+  auto go = [&](bool really) {
+    if (up) {
+      if (mrf) launch<2, EPI_UPSAMPLE, true>(cfg, grid, a, n_len, nullptr, really);
+      else launch<2, EPI_UPSAMPLE, false>(cfg, grid, a, n_len, nullptr, really);
+    } else if (K == 3) launch<3, EPI_LINEAR, false>(cfg, grid, a, n_len, nullptr, really);
+    else if (K == 7) launch<7, EPI_LINEAR, false>(cfg, grid, a, n_len, nullptr, really);
+    else if (K == 11) launch<11, EPI_LINEAR, false>(cfg, grid, a, n_len, nullptr, really);
+    else std::printf("K = %d not instantiated\n", K);
+  };
+  go(true);
+  HC(hipDeviceSynchronize());
+  std::vector<uint16_t> hy((size_t)yoct * yld * 8);
+  HC(hipMemcpy(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost));
+  // reference on a sample of outputs (all of them when the problem is small)
+  auto xin = [&](int c, int t) -> double {
+    if (t < 0 || t >= L) return 0.0;
+    double v = fx[(size_t)c * L + t];
+    if (mrf) {
+      const float s3 = ((fx[(size_t)c * L + t] + fx[((size_t)Cin + c) * L + t]) + fx[((size_t)2 * Cin + c) * L + t]) / 3.0f;
+      v = f16_to_float(f16_rne(s3));
+    }
+    const float h = (float)v;
+    const float act = f16_to_float(f16_rne(h > 0.f ? h : f16_to_float(f16_rne(h * f16_to_float(f16_rne(0.1f))))));
+    return act;
+  };
+  const long long total = (long long)Cout * Lout;
+  const long long stride = total > 400000 ? total / 200000 : 1;
+  double max_err = 0, max_ref = 0;
+  long long checked = 0, bad = 0;
+  for (long long idx = 0; idx < total; idx += stride) {
+    const int co = (int)(idx / Lout), n = (int)(idx % Lout);
+    double acc = bias[co];
+    if (up) {
+      // out[co][n] = sum_ci sum_k x[ci][q - m] wt[ci][co][m up + r], n = q up + r - up/2
+      const int np = n + up / 2;
+      for (int kk = 0; kk < 2 * up; ++kk) {
+        // transposed conv: out[n] += x[i] wt[kk] where n = i up + kk - up/2
+        const int num = np - kk;
+        if (num % up) continue;
+        const int i = num / up;
+        if (i < 0 || i >= L) continue;
+        for (int ci = 0; ci < Cin; ++ci) acc += xin(ci, i) * w[((size_t)ci * Cout + co) * (2 * up) + kk];
+      }
+    } else {
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int k = 0; k < K; ++k) acc += xin(ci, n + k * dil - a.pad) * w[((size_t)co * Cin + ci) * K + k];
+      acc += f16_to_float(hres[((size_t)(co / 8) * yld + n) * 8 + (co % 8)]);
+      acc = acc > 0 ? acc : acc * 0.1f;
+    }
+    const double got = f16_to_float(hy[((size_t)(co / 8) * yld + n) * 8 + (co % 8)]);
+    const double err = std::fabs(got - acc);
+    max_err = std::fmax(max_err, err);
+    max_ref = std::fmax(max_ref, std::fabs(acc));
+    if (err > 2e-3 * std::fmax(1.0, std::fabs(acc))) ++bad;
+    ++checked;
+  }
+  std::printf("check: %lld outputs, max |ref| %.3f, max err %.3e, bad %lld  grid %u x %u\n", checked, max_ref, max_err, bad, grid.x, grid.y);
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    HC(hipEventCreate(&e0));
+    HC(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) go(true);
+    HC(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) go(true);
+    HC(hipEventRecord(e1, nullptr));
+    HC(hipEventSynchronize(e1));
+    float ms = 0;
+    HC(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / iters;
+    const double flop = 2.0 * Cout * Cin * (up ? 2.0 * up : (double)K) * (double)L;
+    std::printf("Cin %d Cout %d K %d dil %d L %d cfg %d up %d: %.2f us per launch, %.1f TFLOP/s (%.3f of 2500)\n", Cin, Cout, K, dil, L, cfg, up, us,
+                flop / us * 1e-6, flop / us * 1e-6 / 2500.0);
+  }
+  return bad ? 1 : 0;
+}
