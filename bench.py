@@ -456,9 +456,9 @@ def main():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE", help="mi355tts_set_option before anything runs (A/B of schedules)")
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="f32 = exact f32 MFMA everywhere (the graded parity mode); bf16x3 = the `half` switch: split-bf16 "
-                         "ResBlock convs (3 x bf16 MFMA per product, f32 accumulate)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
+                    help="f32 = exact f32 MFMA everywhere (the graded parity mode); f16 = the `half` switch: the native fp16 vocoder "
+                         "(fp16 planes, one fp16 MFMA per product); bf16x3 = split-bf16 ResBlock convs (3 x bf16 MFMA per product, f32 planes)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -564,6 +564,8 @@ def main():
     del blob
     if args.precision == "bf16x3":
         eng.set_precision(v, ffi.PRECISION_BF16X3)
+    elif args.precision == "f16":
+        eng.set_precision(v, ffi.PRECISION_F16)
 
     # ---- synthetic utterances (one per step per rank), resident in HBM
     rng = np.random.default_rng(1234 + rank)
@@ -802,11 +804,12 @@ def main():
     def med(x):
         return float(np.median(x))
 
-    # ---- the reference's `half` switch on this backend: split-bf16 ResBlock convs (secondary figure; the
-    # headline above is the exact f32 mode).  Same steps, same method, fewer repeats.
+    # ---- the reference's `half` switch on this backend: the native fp16 vocoder (secondary figure; the headline above is the
+    # exact f32 mode).  Same steps, same method, fewer repeats.  Next to it the split-bf16 mode (f32-class accuracy), in-flight only.
     half = None
+    x3_flight = 0.0
     if args.precision == "f32" and not args.tiny and not args.no_half_mode:
-        eng.set_precision(v, ffi.PRECISION_BF16X3)
+        eng.set_precision(v, ffi.PRECISION_F16)
         run_steps(0, max(W, conc))
         step(W)
         eng.set_profiling(True)
@@ -816,16 +819,20 @@ def main():
             step(i)
         barrier()
         hprof = eng.profile()
+        hprof_kn = eng.profile_kernels()
         eng.set_profiling(False)
         h_single = timed(lambda: run_steps(W, n_utts, threads=1), max(3, repeats // 3))
         h_flight = timed(lambda: run_steps(W, n_utts), max(3, repeats // 3)) if conc > 1 else h_single
+        eng.set_precision(v, ffi.PRECISION_BF16X3)
+        run_steps(0, max(W, conc))
+        x3_flight = med(timed(lambda: run_steps(W, n_utts), max(3, repeats // 3)))
         eng.set_precision(v, ffi.PRECISION_F32)
         step(W)
-        half = (med(h_flight), med(h_single), hprof["conv_mfma.hifigan_resblock"])
+        half = (med(h_flight), med(h_single), hprof["conv_mfma.hifigan_resblock"], hprof, hprof_kn)
 
     stats = torch.tensor([med(t_flight), med(t_single), float(frames), min(t_flight), max(t_flight), min(t_single), med(t_dn), dt_prof,
                           half[0] if half else 0.0, half[1] if half else 0.0, med(t_flight_nc), med(t_voc) if t_voc else 0.0,
-                          host_cpu_s, host_wall_s, med(t_steady) if t_steady else 0.0, med(t_voc_steady) if t_voc_steady else 0.0],
+                          host_cpu_s, host_wall_s, med(t_steady) if t_steady else 0.0, med(t_voc_steady) if t_voc_steady else 0.0, x3_flight],
                          dtype=torch.float64, device=red_dev)
     per_rank = [[float(stats[0]), float(stats[1])]]  # this rank's (in-flight, single-stream) seconds per K-step region
     if use_dist:
@@ -841,7 +848,7 @@ def main():
     else:
         total_frames = float(frames)
     (dt_flight, dt_single, _, dt_flight_min, dt_flight_max, dt_single_min, dt_dn, dt_prof, dt_half_flight, dt_half_single, dt_flight_nc, dt_voc,
-     host_cpu_max, host_wall_max, dt_steady, dt_voc_steady) = (float(x) for x in stats)
+     host_cpu_max, host_wall_max, dt_steady, dt_voc_steady, dt_x3_flight) = (float(x) for x in stats)
 
     # ---- BASELINE config 3: 256 utterances, LPT-sharded over the ranks, ordered gather (strong scaling)
     c3 = None
@@ -1013,7 +1020,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 MFMA, f32 accumulate) in the ResBlock convs and upsamplers, f32 elsewhere",
+            "dtype": {"f32": "f32", "f16": "f16 (fp16 planes and weights, f32 accumulate) in the whole vocoder, f32 in GlowTTS",
+                      "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate) in the ResBlock convs and upsamplers, f32 elsewhere"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": f"en-us ljspeech GlowTTS + hifi_gan '{quality}', batch={B}, {args.ids} phoneme ids per utterance "
@@ -1083,36 +1091,40 @@ def main():
                 "utterances_per_sec": world * K * B / dt_dn,
             },
             "half_mode": None if not half else {
-                "dtype": "bf16x3: the HiFi-GAN ResBlock convs and upsamplers on the bf16 matrix cores with split operands "
-                         "(x = hi + lo, three bf16 MFMAs per product, f32 accumulate; conv_bf16.h); GlowTTS, conv_pre / conv_post and "
-                         "the narrow stages of 'medium' stay f32",
-                "what": "the reference's `half` switch (larynx/hifi_gan.py:96-97) on this backend; NOT the headline — reported next to it",
-                "parity": "waveform RMS <= 2.9e-6 vs the reference's f32 output on the golden set, int16 within 1 LSB — both asserted "
-                          "(tests/test_gpu_parity.py::test_bf16x3_mode_against_the_reference and ::test_bf16x3_fused_call_against_the_reference; "
-                          "north_star bar 1e-4)",
+                "dtype": "f16: the native fp16 vocoder — fp16 weights, fp16 activation planes in HBM between ALL layers (conv_pre, upsamplers, every "
+                         "ResBlock conv, conv_post), one v_mfma_f32_32x32x16_f16 per product, f32 accumulate (csrc/conv_f16.h, hifigan_f16.h); "
+                         "GlowTTS stays f32 (mi355tts_model_set_precision reports the switch as a no-op there)",
+                "what": "the reference's `half` switch (`.half()` on the generator, larynx/hifi_gan.py:96-97) on this backend; NOT the headline — reported next to it",
+                "parity": "waveform error vs the reference's f32 output no larger than the reference's OWN generator under .half() on the same "
+                          "input (tests/golden/*.npz: ref_half_rms, made by oracle/make_golden.py); asserted per golden case in "
+                          "tests/test_gpu_parity.py::test_f16_mode_against_the_reference and ::test_f16_fused_call_against_the_reference",
                 "utterances_per_sec": world * K * B / dt_half_flight,
                 "ms_per_step": 1e3 * dt_half_flight / K,
                 "latency_ms_single_stream": 1e3 * dt_half_single / K,
                 "x_realtime_per_gpu": audio_s / (dt_half_flight * world),
                 "resblock_class_ms_per_step": half[2]["ms"] / K,
-                "resblock_class_f32_equivalent_tflops": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 if half[2]["ms"] > 0 else None,
-                # the split mode issues THREE bf16 MFMAs per f32 product (hi*hi + hi*lo + lo*hi): the matrix pipes do 3x the
-                # algorithmic FLOPs, and that executed rate is what is priced against the dense bf16 peak
+                "profile_ms_per_step": {k: c["ms"] / K for k, c in half[3].items() if c["launches"]},
+                # ONE fp16 MFMA per product: executed matrix work = the algorithmic FLOPs
                 "roofline": None if half[2]["ms"] <= 0 else {
-                    "kernel": "HiFi-GAN ResBlock launches in the split-bf16 mode: conv_bf16_group_kernel (256/128-channel stages) + "
-                              "pair16_group_kernel (fused conv pairs, 64/32-channel stages), HIP events per launch, single stream",
+                    "kernel": "HiFi-GAN ResBlock launches in the fp16 mode: conv_f16_group_kernel (the three MRF chains' same-geometry convs per launch), "
+                              "HIP events per launch, single stream",
                     "bound": "mfma",
-                    "achieved": 3.0 * half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12,
+                    "achieved": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12,
                     "peak": BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
-                    "frac": 3.0 * half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
-                    "note": "executed bf16 MFMA work (3 x the algorithmic f32 FLOPs) / dense bf16 peak; the f32-equivalent rate above is what a "
-                            "caller sees; PMC of these kernels: profiles/r05_bf16x3_pmc_by_kernel.csv",
+                    "frac": half[2]["flop"] / (half[2]["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                    "note": "algorithmic FLOPs (one MFMA per product) / dense fp16 peak (= the bf16 figure); launches measured one call at a time",
                     "launches": half[2]["launches"],
                     "avg_launch_us": 1e3 * half[2]["ms"] / max(1, half[2]["launches"]),
-                    # raw event durations here; the same figure without the empty-event-pair cost (see roofline.timing)
-                    "frac_minus_event_overhead": 3.0 * half[2]["flop"] / (max(half[2]["ms"] - 1e-3 * ev_us * half[2]["launches"], 0.5 * half[2]["ms"]) * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                    "frac_minus_event_overhead": half[2]["flop"] / (max(half[2]["ms"] - 1e-3 * ev_us * half[2]["launches"], 0.5 * half[2]["ms"]) * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                    "by_kernel": by_kernel_table(half[4]),
                 },
+            },
+            "bf16x3_mode": None if not half else {
+                "dtype": "bf16x3: ResBlock convs and upsamplers on the bf16 matrix cores with split operands (three MFMAs per product, f32 planes; "
+                         "conv_bf16.h) — the ACCURATE reduced mode: waveform RMS <= 2.9e-6 vs the reference's f32 output on the golden set",
+                "utterances_per_sec": world * K * B / dt_x3_flight if dt_x3_flight > 0 else None,
+                "ms_per_step": 1e3 * dt_x3_flight / K,
             },
             "weight_broadcast_seconds": broadcast_s if use_dist else None,
             "per_rank": {

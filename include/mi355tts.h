@@ -118,15 +118,24 @@ int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, int root, flo
 /* The reference's `half` switch (TextToSpeechModelConfig.half / VocoderModelConfig.half,
  * larynx/constants.py:58,85; `.half()` at larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97).
  * MI355TTS_PRECISION_F32 (default): exact f32 MFMA everywhere — the parity mode.
- * MI355TTS_PRECISION_BF16X3: the HiFi-GAN ResBlock convs (93 % of the path's FLOPs) run on the bf16 matrix cores with split operands (x = hi + lo, three bf16 MFMAs per
- * product, f32 accumulate): ~1e-5 relative error per layer instead of exact f32.  GlowTTS models
- * accept the call and keep computing in f32.
- * MI355TTS_PRECISION_BF16: the same kernels with ONE bf16 MFMA per product (operands rounded to bf16, f32
- * accumulate) — plain reduced precision like the reference's `.half()`: ~3e-3 relative per product, waveform
- * RMS ~1e-3; no faster than the split mode on these shapes (both are bound by operand delivery). */
+ * MI355TTS_PRECISION_F16: the native 16-bit mode, the analogue of the reference's `.half()` on the generator (hifi_gan/models.py
+ * :186-202 under half weights and activations): fp16 weights, fp16 activation planes in HBM between ALL layers of the vocoder
+ * (conv_pre, upsamplers, every ResBlock conv of every stage, conv_post), ONE v_mfma_f32_32x32x16_f16 per product, f32 accumulation;
+ * bias, residual and activation are applied to the f32 accumulator before its one rounding to fp16 (csrc/conv_f16.h,
+ * csrc/hifigan_f16.h).  Accuracy is that of a half-precision forward (tests compare with the reference's own generator run
+ * under .half() / .bfloat16()).  Returns MI355TTS_ERR_INVALID with the reason when the vocoder's geometry is not covered
+ * (channel counts not multiples of 8, upsampler kernel != 2 x stride, taps outside 3 / 5 / 7 / 11).
+ * MI355TTS_PRECISION_BF16X3: the accurate reduced mode — the HiFi-GAN ResBlock convs and upsamplers run on the bf16 matrix cores
+ * with split operands (x = hi + lo, three bf16 MFMAs per product, f32 accumulate, f32 planes): ~1e-5 relative error per layer.
+ * MI355TTS_PRECISION_BF16: the BF16X3 kernels with ONE bf16 MFMA per product (kept for A/B runs).
+ * GlowTTS models always compute in exact f32 (4 % of the path's FLOPs, launch-bound: no speed to buy): a request for any other
+ * precision on a GlowTTS model changes nothing and returns MI355TTS_PRECISION_NOOP (= 1, a positive status: not an error, not a
+ * silent success); MI355TTS_PRECISION_F32 returns 0. */
 #define MI355TTS_PRECISION_F32 0
 #define MI355TTS_PRECISION_BF16X3 1
 #define MI355TTS_PRECISION_BF16 2
+#define MI355TTS_PRECISION_F16 3
+#define MI355TTS_PRECISION_NOOP 1 /* return value: accepted, no effect on this model */
 int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision);
 
 /* ---- GlowTTS: replaces GlowTextToSpeech.phonemes_to_mels --------------------

@@ -221,7 +221,10 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   w->o_rb_conv = ctx->rb_conv.load();
   w->o_rb_pair = ctx->rb_pair.load();
   w->o_group_promote = ctx->group_promote.load();
-  const bool split_out = hifi_split_out(opt_serial, h);
+  const int prec = hm->precision.load();
+  const bool f16 = prec == MI355TTS_PRECISION_F16;  // the native fp16 generator (hifigan_f16.h): its own schedule, chains always write their own planes
+  if (f16 && !hm->f16_ok) return fail(MI355TTS_ERR_INVALID, "internal: fp16 mode on a vocoder it does not cover");
+  const bool split_out = f16 || hifi_split_out(opt_serial, h);
   // grouped (default): the chains stay on ONE stream and the same-geometry launches of a step go out as
   // one grouped launch (conv_group_kernel / pair_group_kernel) — the chip is filled from one launch, with
   // no stream fork/join and independently of what else is in flight.  "mrf_group" = 0 restores the
@@ -247,7 +250,6 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   static const int rb_env = [] { const char* e = std::getenv("MI355TTS_RB_TILES"); return e ? std::atoi(e) : 0; }();
   const int rb_tiles = rb_env > 0 ? rb_env : 1024;
   const int voc_host_len = B == 1 ? mel->frames[0] : -1;
-  const int prec = hm->precision.load();
   int pads = call.pad_before + call.pad_after;
   bool any_f32 = wav_f32 != nullptr, any_i16 = wav_i16 != nullptr;
   if (prow) {
@@ -272,6 +274,15 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   const size_t o_wav2 = lay.o_wav2, o_fbuf = lay.o_fbuf;
   const int* d_frames = mel->frames_dev;
 
+  static const bool voc_out_off = [] { const char* e = std::getenv("MI355TTS_NO_VOC_OUT"); return e && std::atoi(e) != 0; }();
+  const long long peak_ld = (long long)(Nld / POST_TW + 2);
+  bool peak_parts_ready = false;  // post_conv_kernel left the per-workgroup maxima of the FINAL waveform
+  bool vo = true;
+  if (f16) {
+    if ((size_t)((mel->M + 7) / 8) * F * 16 > lay.plane * sizeof(float)) return fail(MI355TTS_ERR_INVALID, "internal: mel octets exceed a plane buffer");
+    peak_parts_ready = any_i16 && !denoise;
+    CHECK(hifigan_body_f16(ctx, w, hm, mel, buf, wav, Nld, peak_parts_ready ? reinterpret_cast<float*>(peak) : nullptr, peak_ld, voc_host_len, s));
+  } else {
   // stage input: `cur[0]` alone, or the nk chain outputs cur[0..nk) still to be averaged
   float* cur[3] = {buf[0], nullptr, nullptr};
   int ncur = 1;
@@ -478,11 +489,8 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   }
   // Option "voc_out" (default 1): conv_post + tanh + the rows' peaks in ONE dedicated launch and the delivery of the rows in one
   // more (voc_out.h); 0 = the generic conv tile, zero_tail, absmax, to_int16 and a copy / fill per piece of every row.
-  static const bool voc_out_off = [] { const char* e = std::getenv("MI355TTS_NO_VOC_OUT"); return e && std::atoi(e) != 0; }();
-  const bool vo = !voc_out_off && ctx->voc_out.load() && hm->post_C == ch && hm->post.K == 7 && ldin % 4 == 0;
+  vo = !voc_out_off && ctx->voc_out.load() && hm->post_C == ch && hm->post.K == 7 && ldin % 4 == 0;
   if (prow && !vo) return fail(MI355TTS_ERR_INVALID, "internal: per-row outputs need the voc_out tail");
-  const long long peak_ld = (long long)(Nld / POST_TW + 2);
-  bool peak_parts_ready = false;  // post_conv_kernel left the per-workgroup maxima of the FINAL waveform
   if (vo) {  // x = tanh(conv_post(leaky_relu(x)))  — default slope 0.01 (models.py:198-200)
     PostArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -520,6 +528,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     a.out_act = ACT_TANH;
     CHECK(launch_conv(ctx, w, hm->post, a, EPI_LINEAR, B, Lin, KC_VOC_IO, nullptr, 1024, voc_host_len));
   }
+  }  // !f16
   if (denoise) {  // HiFiGanVocoder.denoise (larynx/hifi_gan.py:171-179)
     ProfScope ps(ctx, w, KC_SMALL, 0);
     float* wav2 = (float*)(base + o_wav2);

@@ -252,12 +252,32 @@ struct MrfStage {
   int dil[3][MRF_MAX_STEPS] = {};
   double mac_per_col = 0;  // algorithmic MACs per output column (all 18 convs)
 };
+// one conv of the native fp16 vocoder (conv_f16.h): fp16 A fragments in the model's fp16 arena, f32 bias in the float arena
+struct HConvW {
+  size_t w_off = 0, b_off = 0;  // uint16 elements into arenaH; floats into the model arena
+  const uint4* w = nullptr;
+  const float* bias = nullptr;
+  int mtiles = 0, nslab = 0, K = 0, rows = 0, Cin = 0;
+};
+struct HResConv {
+  HConvW c1, c2;
+};
 struct HifiModel {
   mi355tts_hifigan_hparams hp;
   int device = 0;
   float* arena = nullptr;
   uint16_t* arena16 = nullptr;  // split-bf16 weight fragments of the ResBlock convs
-  std::atomic<int> precision{0};  // 0 = exact f32 MFMA, 1 = split-bf16 (3 x bf16 MFMA) for the wide ResBlock convs
+  // the native fp16 mode (MI355TTS_PRECISION_F16): every conv of the generator packed for conv_f16.h; f16_ok = the model's
+  // geometry is one the fp16 tiles cover (f16_why says what is not)
+  uint16_t* arenaH = nullptr;
+  bool f16_ok = false;
+  std::string f16_why;
+  HConvW h_pre;
+  std::vector<HConvW> h_ups;
+  std::vector<std::vector<std::vector<HResConv>>> h_rb;  // [stage][kernel][dilation index]
+  // 0 = exact f32 MFMA, 1 = split-bf16 (3 x bf16 MFMA) for the wide ResBlock convs, 2 = the same with one bf16 MFMA,
+  // 3 = native fp16 (fp16 planes, one fp16 MFMA per product, the whole generator)
+  std::atomic<int> precision{0};
   DevConv pre, post;
   size_t post_w_off = 0, post_b_off = 0;  // conv_post's raw [C][7] weight and bias (post_conv_kernel)
   int post_C = 0;
@@ -274,6 +294,7 @@ struct HifiModel {
     DeviceScope ds(device);
     if (arena) hipFree(arena);
     if (arena16) hipFree(arena16);
+    if (arenaH) hipFree(arenaH);
     if (bias_spec) hipFree(bias_spec);
   }
 };

@@ -39,12 +39,14 @@
 #include "coltile.h"
 #include "voc_out.h"
 #include "small_kernels.h"
+#include "conv_f16.h"
 #include "weights_pack.h"
 
 using namespace mi355tts;
 #include "host_models.h"
 #include "host_context.h"
 #include "host_launch.h"
+#include "hifigan_f16.h"
 
 // ------------------------------------------------------------------ C ABI: basics
 extern "C" int mi355tts_abi_version(void) { return MI355TTS_ABI_VERSION; }
@@ -427,6 +429,11 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     d.mtiles16 = p.mtiles;
     d.nslab16 = p.nslab;
   };
+  // the native fp16 mode's packing of every conv (hifigan_f16.h), when the geometry is one its tiles cover
+  hm->f16_why = hifi_f16_unsupported(h);
+  hm->f16_ok = hm->f16_why.empty();
+  HPackSink hsink;
+  hsink.ab = &ab;
   const int C0 = h.upsample_initial_channel;
 #define TAKE(var, name, n)                         \
   const float* var = bl.take((name).c_str(), (n)); \
@@ -435,6 +442,7 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     TAKE(w, std::string("conv_pre.weight"), (int64_t)C0 * h.num_mels * 7);
     TAKE(b, std::string("conv_pre.bias"), C0);
     hm->pre = add_conv(ab, w, b, C0, h.num_mels, 7, ROWS_PLAIN);
+    if (hm->f16_ok) hm->h_pre = add_conv_h(hsink, w, b, C0, h.num_mels, 7);
   }
   int ch = C0;
   hm->hop = 1;
@@ -446,6 +454,7 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     TAKE(w, "ups." + std::to_string(i) + ".weight", (int64_t)cin * cout * ku);
     TAKE(b, "ups." + std::to_string(i) + ".bias", cout);
     hm->ups.push_back(add_conv(ab, w, b, cout, cin, ku, ROWS_UPSAMPLE, u));
+    if (hm->f16_ok) hm->h_ups.push_back(add_ups_h(hsink, w, b, cout, cin, u));
     if (cin % 32 == 0 && (cout * u) % 32 == 0 && ku / u == 2) {
       // split-bf16 fragments of the polyphase form (virtual rows v = co * u + r, taps k = 0, 1 <-> m = 1, 0; see add_conv)
       DevConv& d = hm->ups.back();
@@ -462,6 +471,10 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
     }
     ch = cout;
     hm->rb[i].resize(h.num_kernels);
+    if (hm->f16_ok) {
+      hm->h_rb.resize(h.num_upsamples);
+      hm->h_rb[i].resize(h.num_kernels);
+    }
     // narrow stages additionally get the packing of the one-launch MRF kernel (mrf_small.h): ResBlock1 chains
     // with taps (3, 7, 11), <= 3 dilation steps and a receptive half-width within the staged halo
     MrfStage ms;
@@ -496,6 +509,12 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
           rc.c2 = add_conv(ab, w2, b2, ch, ch, k, ROWS_PLAIN);
           add16(rc.c1, w1, ch, k);
           add16(rc.c2, w2, ch, k);
+          if (hm->f16_ok) {
+            HResConv hr;
+            hr.c1 = add_conv_h(hsink, w1, b1, ch, ch, k);
+            hr.c2 = add_conv_h(hsink, w2, b2, ch, ch, k);
+            hm->h_rb[i][j].push_back(hr);
+          }
           if (ms.ok) {
             const float* ws[2] = {w1, w2};
             const float* bs[2] = {b1, b2};
@@ -519,6 +538,11 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
           TAKE(b1, rb + ".convs." + std::to_string(d) + ".bias", ch);
           rc.c1 = add_conv(ab, w1, b1, ch, ch, k, ROWS_PLAIN);
           add16(rc.c1, w1, ch, k);
+          if (hm->f16_ok) {
+            HResConv hr;
+            hr.c1 = add_conv_h(hsink, w1, b1, ch, ch, k);
+            hm->h_rb[i][j].push_back(hr);
+          }
         }
         hm->rb[i][j].push_back(rc);
       }
@@ -565,6 +589,19 @@ extern "C" int mi355tts_load_hifigan(mi355tts_ctx* ctx, const mi355tts_hifigan_h
   }
   auto fix16 = [&](DevConv& c) { c.w16 = c.mtiles16 ? (const void*)(hm->arena16 + c.w16_off) : nullptr; };
   const float* A = hm->arena;
+  if (hm->f16_ok) {
+    hipError_t e = hipMalloc(&hm->arenaH, hsink.w.size() * sizeof(uint16_t) + 256);
+    if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc fp16 weight arena: %s", hipGetErrorString(e));
+    HIPCHECK(hipMemcpy(hm->arenaH, hsink.w.data(), hsink.w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    fix_h(hm->h_pre, hm->arenaH, A);
+    for (auto& c : hm->h_ups) fix_h(c, hm->arenaH, A);
+    for (auto& st : hm->h_rb)
+      for (auto& kk : st)
+        for (auto& rc : kk) {
+          fix_h(rc.c1, hm->arenaH, A);
+          if (h.resblock_type == 1) fix_h(rc.c2, hm->arenaH, A);
+        }
+  }
   fix(hm->pre, A);
   fix(hm->post, A);
   for (auto& c : hm->ups) {
@@ -652,16 +689,20 @@ extern "C" int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, in
 
 extern "C" int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int precision) {
   if (!ctx) return fail(MI355TTS_ERR_INVALID, "ctx null");
-  if (precision != MI355TTS_PRECISION_F32 && precision != MI355TTS_PRECISION_BF16X3 && precision != MI355TTS_PRECISION_BF16)
+  if (precision != MI355TTS_PRECISION_F32 && precision != MI355TTS_PRECISION_BF16X3 && precision != MI355TTS_PRECISION_BF16 &&
+      precision != MI355TTS_PRECISION_F16)
     return fail(MI355TTS_ERR_INVALID, "unknown precision %d", precision);
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto v = ctx->hifi.find(model);
   if (v != ctx->hifi.end()) {
+    if (precision == MI355TTS_PRECISION_F16 && !v->second->f16_ok)
+      return fail(MI355TTS_ERR_INVALID, "fp16 mode is not available for this vocoder: %s", v->second->f16_why.c_str());
     v->second->precision.store(precision);
     return 0;
   }
-  // GlowTTS (4 % of the path's FLOPs) always computes in exact f32: the switch is accepted and has no effect
-  if (ctx->glow.find(model) != ctx->glow.end()) return 0;
+  // GlowTTS (4 % of the path's FLOPs) always computes in exact f32: a reduced-precision request is REPORTED as having no
+  // effect (a distinct positive status, not an error and not a silent success); F32 is what it runs anyway
+  if (ctx->glow.find(model) != ctx->glow.end()) return precision == MI355TTS_PRECISION_F32 ? 0 : MI355TTS_PRECISION_NOOP;
   return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
 }
 

@@ -55,6 +55,8 @@ class HipGlowTextToSpeech(TextToSpeechModel):
             names = [n for n, _ in ffi.manifest(self.engine.lib, ffi.glow_hparams_c(self.hparams))]
             state_dict = load_state_dict(ckpt, "model", manifest_names=names, n_split=self.hparams.n_split)
         self.model_id = self.engine.load_glow(self.hparams, state_dict)
+        if config.half and self.engine.set_precision(self.model_id, ffi.PRECISION_F16) == ffi.PRECISION_NOOP:
+            _LOGGER.debug("half: the acoustic model computes in f32 (the library reports the switch as a no-op for GlowTTS)")
         self.noise_scale = 0.667
         self.length_scale = 1.0
         self._audio_settings: typing.Optional[AudioSettings] = None

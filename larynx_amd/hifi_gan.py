@@ -44,11 +44,19 @@ class HipHiFiGanVocoder(VocoderModel):
             names = [n for n, _ in ffi.manifest(self.engine.lib, ffi.hifigan_hparams_c(self.hparams))]
             state_dict = load_state_dict(ckpt, "generator", manifest_names=names)
         self.model_id = self.engine.load_hifigan(self.hparams, state_dict)
-        # `half` (larynx/hifi_gan.py:96-97 calls `.half()` on the generator): the wide ResBlock convs move to the
-        # bf16 matrix cores with split operands (3 x bf16 MFMA per product, f32 accumulate) — see conv_bf16.h
+        # `half` (larynx/hifi_gan.py:96-97 calls `.half()` on the generator): the native fp16 vocoder — fp16 weights and
+        # activation planes, one fp16 MFMA per product, f32 accumulate (csrc/conv_f16.h).  A vocoder whose geometry the fp16
+        # tiles do not cover runs the split-bf16 mode instead (f32 planes, 3 x bf16 MFMA per product), and says so.
         self.half = bool(config.half)
+        self.precision = ffi.PRECISION_F32
         if self.half:
-            self.engine.set_precision(self.model_id, ffi.PRECISION_BF16X3)
+            try:
+                self.engine.set_precision(self.model_id, ffi.PRECISION_F16)
+                self.precision = ffi.PRECISION_F16
+            except ffi.Mi355ttsError as e:
+                _LOGGER.warning("half: %s; using the split-bf16 mode", e)
+                self.engine.set_precision(self.model_id, ffi.PRECISION_BF16X3)
+                self.precision = ffi.PRECISION_BF16X3
         self.denoiser_strength = float(config.denoiser_strength)
 
     def mels_to_audio(self, mels: ARRAY_OR_TENSOR, settings: typing.Optional[SettingsType] = None) -> np.ndarray:

@@ -249,6 +249,26 @@ def main():
             wav_absmean=float(np.abs(wav).mean()),
             wav_absmax=float(np.abs(wav).max()),
         )
+        # --- what the reference's own `half` switch costs on this case: ITS generator under .half() (larynx/hifi_gan.py:96-97;
+        # the caller hands it half mels, larynx/__init__.py:244-247) and under .bfloat16(), on the same vocoder input, against its
+        # own f32 waveform.  The HIP library's reduced modes are held to these figures (tests/test_gpu_parity.py).
+        import copy
+
+        import torch
+
+        half_extra = {}
+        for tag, dt in (("half", torch.float16), ("bf16", torch.bfloat16)):
+            hmodel = copy.deepcopy(vmodel).to(dt)
+            with torch.no_grad():
+                hw = hmodel(torch.from_numpy(mel_voc[None]).to(dt)).squeeze(0).float().cpu().numpy()[0]
+            h16 = ra.audio_float_to_int16(hw[None]).squeeze()
+            e[f"ref_{tag}_rms"] = float(np.sqrt(np.mean((hw - wav) ** 2)))
+            e[f"ref_{tag}_max"] = float(np.abs(hw - wav).max())
+            e[f"ref_{tag}_i16"] = int(np.abs(h16.astype(np.int32) - wav_i16.astype(np.int32)).max())
+            half_extra[f"ref_{tag}_rms"] = np.float32(e[f"ref_{tag}_rms"])
+            half_extra[f"ref_{tag}_max"] = np.float32(e[f"ref_{tag}_max"])
+            half_extra[f"ref_{tag}_i16"] = np.int32(e[f"ref_{tag}_i16"])
+            del hmodel
         report[name] = e
         print(name, json.dumps(e))
         assert e["mel"] < 2e-4 and e["wav_rms"] < 2e-5 and e["i16"] <= 1, e
@@ -273,7 +293,8 @@ def main():
             extra = dict(denoiser_strength=np.float32(strength), bias_spec=bias_spec[0, :, 0].astype(np.float32),
                          wav_denoised=den[0].astype(np.float32), wav_denoised_i16=den_i16, wav_denoised_stride=np.int32(1))
         if name.startswith("batch8/"):
-            batch_rows.append(dict(ids=ids, mel=mel.astype(np.float32), wav=wav.astype(np.float32), wav_i16=wav_i16))
+            batch_rows.append(dict(ids=ids, mel=mel.astype(np.float32), wav=wav.astype(np.float32), wav_i16=wav_i16,
+                                   ref_half_rms=half_extra["ref_half_rms"], ref_bf16_rms=half_extra["ref_bf16_rms"]))
             continue
         keep_wav = wav  # full waveforms (round 1 stored 1 sample in 7 of the long ones)
         np.savez_compressed(
@@ -290,13 +311,14 @@ def main():
             glow=json.dumps(ghp.to_config()),
             vocoder=json.dumps(vhp.to_config()),
             **extra,
+            **half_extra,
         )
     (GOLDEN / "batch8").mkdir(exist_ok=True)
     np.savez_compressed(
         GOLDEN / "batch8" / "thorsten_medium_batch8.npz",
         noise_seed=np.int32(4), noise_scale=np.float32(0.667), length_scale=np.float32(0.5),
         glow=json.dumps(HP.THORSTEN.to_config()), vocoder=json.dumps(HP.HIFIGAN_MEDIUM.to_config()),
-        **{f"{k}{b}": r[k] for b, r in enumerate(batch_rows) for k in ("ids", "mel", "wav")},  # int16 = audio_float_to_int16(wav)
+        **{f"{k}{b}": r[k] for b, r in enumerate(batch_rows) for k in ("ids", "mel", "wav", "ref_half_rms", "ref_bf16_rms")},  # int16 = audio_float_to_int16(wav)
     )
     (GOLDEN / "oracle_vs_reference.json").write_text(json.dumps(report, indent=1, sort_keys=True))
 

@@ -32,4 +32,5 @@ def load_batch8():
         ids=[z[f"ids{b}"] for b in range(8)],
         mel=[z[f"mel{b}"] for b in range(8)],
         wav=[z[f"wav{b}"] for b in range(8)],
+        ref_half_rms=[float(z[f"ref_half_rms{b}"]) for b in range(8)],  # the reference's generator under .half() vs its own f32 waveform
     )

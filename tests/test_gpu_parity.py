@@ -631,6 +631,106 @@ def test_plain_bf16_mode_documented_tolerance(gpu_engine):
     assert out["bf16"] <= 1e-2 and out["bf16x3"] <= 1e-4 and out["bf16"] > 20 * out["bf16x3"]
 
 
+F16_CASES = ["ljspeech_high_echo", "ljspeech_high_S120", "ljspeech_high_P200", "ljspeech_high_short5", "ljspeech_medium_dave_ls12", "ljspeech_low_echo",
+             "thorsten_medium_veg"]
+
+
+@pytest.mark.parametrize("name", F16_CASES)
+def test_f16_mode_against_the_reference(gpu_engine, name):
+    """The reference's `half` switch = `.half()` on the generator (larynx/hifi_gan.py:96-97).  Here: the native fp16 vocoder
+    (csrc/conv_f16.h).  The tolerance is anchored on the reference itself: oracle/make_golden.py ran the reference's OWN
+    generator under .half() on this case's vocoder input and stored its RMS / max error against its own f32 waveform
+    (`ref_half_rms`, `ref_half_max`); the HIP mode must be no worse — on the float waveform and on the int16 samples.  Every
+    layer honours the switch (no f32 / bf16 vocoder kernel launches), and the exact mode is untouched by switching back."""
+    from larynx_amd import ffi
+
+    c = load_case(name)
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    exact, _ = gpu_engine.hifigan_infer(v, mb)
+    assert gpu_engine.set_precision(v, ffi.PRECISION_F16) == 0
+    try:
+        gpu_engine.profile_reset()
+        wav, i16 = gpu_engine.hifigan_infer(v, mb)
+        counts = gpu_engine.kernel_counts()
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+    again, _ = gpu_engine.hifigan_infer(v, mb)
+    assert np.array_equal(exact, again)
+    vh = c["voc_hp"]
+    per_step = 2 if vh.resblock == "1" else 1
+    assert counts.get("conv_f16_group_kernel", 0) == len(vh.upsample_rates) * len(vh.resblock_dilation_sizes[0]) * per_step
+    assert counts.get("conv_f16_kernel", 0) == 1 + len(vh.upsample_rates) and counts.get("post_f16_kernel", 0) == 1
+    for k in ("conv_mfma_kernel", "conv_mfma_kernel.m128", "rb_group_kernel", "rb_group_kernel.snake", "rb_pair_group_kernel", "conv_bf16_group_kernel",
+              "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "post_conv_kernel"):
+        assert counts.get(k, 0) == 0, k
+    rms = float(np.sqrt(np.mean((wav[0] - c["wav"]) ** 2)))
+    mx = float(np.abs(wav[0] - c["wav"]).max())
+    d16 = int(np.abs(i16[0].astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
+    print(f"f16 {name}: rms {rms:.3e} (reference .half(): {float(c['ref_half_rms']):.3e})  max {mx:.3e} ({float(c['ref_half_max']):.3e})  "
+          f"int16 {d16} LSB ({int(c['ref_half_i16'])})")
+    assert rms <= float(c["ref_half_rms"]) and mx <= 1.5 * float(c["ref_half_max"]) and d16 <= 1.5 * int(c["ref_half_i16"]), (rms, mx, d16)
+    assert not np.array_equal(exact, wav)
+
+
+@pytest.mark.parametrize("name", ["ljspeech_high_S120", "ljspeech_medium_dave_ls12"])
+def test_f16_fused_call_against_the_reference(gpu_engine, name):
+    """The path `half=True` really takes — ids -> ONE fused `mi355tts_synthesize` call with the vocoder in fp16 (what
+    bench.py's half_mode leg times): frames identical to the reference's, the acoustic model untouched (f32: the library reports
+    the switch as a no-op there), waveform within the reference's own .half() error against the f32 golden."""
+    from larynx_amd import ffi
+
+    c = load_case(name)
+    (gsd, g), (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    s = ljspeech_audio_settings()
+    gpu_engine.set_precision(v, ffi.PRECISION_F16)
+    assert gpu_engine.set_precision(g, ffi.PRECISION_F16) == ffi.PRECISION_NOOP
+    try:
+        frames, wav, i16 = gpu_engine.synthesize(g, v, c["ids"], float(c["noise_scale"]), float(c["length_scale"]), noise=c["noise"],
+                                                 audio_settings=s, want_float=True)
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+    assert int(frames[0]) == c["mel"].shape[1]
+    n = int(frames[0]) * c["voc_hp"].hop
+    rms = float(np.sqrt(np.mean((wav[0, :n] - c["wav"]) ** 2)))
+    d16 = int(np.abs(i16[0, :n].astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
+    print(f"f16 fused {name}: rms {rms:.3e} (reference .half(): {float(c['ref_half_rms']):.3e}) int16 {d16} LSB")
+    assert rms <= float(c["ref_half_rms"]) and d16 <= 1.5 * int(c["ref_half_i16"]), (rms, d16)
+
+
+def test_f16_config4_batch_rows(gpu_engine):
+    """BASELINE config 4 (thorsten + 'medium', B = 8 ragged) with the vocoder in fp16: every row within the reference's own
+    .half() error for THAT row, padded tails exactly 0, and a row inside the batch equal to its solitary call bit for bit
+    (the ragged grid deals a row its own tiles: same tiles, same summation order)."""
+    from larynx_amd import ffi
+    from tests.golden_util import load_batch8
+
+    c = load_batch8()
+    ghp, vhp = c["glow_hp"], c["voc_hp"]
+    (gsd, g), (vsd, v) = models(gpu_engine, ghp, vhp)
+    s = ljspeech_audio_settings()
+    mel = gpu_engine.glow_infer(g, c["ids"], c["noise_scale"], c["length_scale"], noise=c["noise"], audio_settings=s)
+    hop = vhp.hop
+    gpu_engine.set_precision(v, ffi.PRECISION_F16)
+    try:
+        wav, i16 = gpu_engine.hifigan_infer(v, mel)
+        for b in range(8):
+            n = c["mel"][b].shape[1] * hop
+            rms = float(np.sqrt(np.mean((wav[b, :n] - c["wav"][b]) ** 2)))
+            assert rms <= c["ref_half_rms"][b], (b, rms, c["ref_half_rms"][b])
+            assert np.all(wav[b, n:] == 0) and np.all(i16[b, n:] == 0)
+        for b in (0, 5):
+            one = gpu_engine.glow_infer(g, c["ids"][b], c["noise_scale"], c["length_scale"], noise=c["noise"][b], audio_settings=s)
+            w1, _ = gpu_engine.hifigan_infer(v, one)
+            n = int(one.frames[0]) * hop
+            if np.array_equal(one.numpy("vocoder")[0], mel.numpy("vocoder")[b, :, : int(one.frames[0])]):  # same mel bits in -> same bits out
+                np.testing.assert_array_equal(wav[b, :n], w1[0, :n])
+            else:
+                assert np.sqrt(np.mean((wav[b, :n] - w1[0, :n]) ** 2)) <= 2 * c["ref_half_rms"][b]
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+
+
 def test_broadcast_weights_over_a_callers_rccl_communicator(gpu_engine):
     """`mi355tts_broadcast_weights`: the caller owns an RCCL communicator — here a one-rank
     one made with ctypes on the system's librccl —, the folded weight blob sits in device memory, the library
