@@ -78,18 +78,26 @@ __device__ __forceinline__ uint4 lrelu_h8(const uint4& v, _Float16 slope) {
 #ifndef F16_ADIST
 #define F16_ADIST 6  // weight fragments in flight ahead of the MFMAs that use them (steps)
 #endif
+#ifndef F16_MIN_WAVES
+#define F16_MIN_WAVES 1  // __launch_bounds__' second argument: waves per SIMD the register allocation must leave room for
+#endif
 #ifndef F16_BDIST
 #define F16_BDIST 2  // LDS fragments ahead (steps)
 #endif
 
-template <int NB, int WN, int HALO, int CH>
+// RING = staged chunks the workgroup keeps in LDS: 3 = the ring (any number of chunks); 1 / 2 = a conv of at most that many chunks,
+// all staged in the prologue (a third or two thirds of the ring's LDS: more workgroups per CU on the narrow stages)
+template <int NB, int WN, int HALO, int CH, int RING = 3>
 constexpr int conv_f16_lds_units() {
-  return 3 * (CH / 8) * (32 * NB * WN + HALO);  // a ring of three staged chunks
+  return RING * (CH / 8) * (32 * NB * WN + HALO);
 }
 
-template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int EPI, bool MRF>
-__device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile_x, const int tile_y, const int b, uint4* __restrict__ xs) {
-  static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "f16 tile epilogues");
+// The main loop of a tile: acc[mb][nb] += W (m-tiles mt0 .. mt0 + MB) x X over all input channels and taps, for the T_T computed
+// columns whose first one is implicit-GEMM column t0 (input column t0 - a.pad at tap 0).  `a.w`, `a.nslab`, `a.Cin`, `a.dil`, `a.pad`,
+// `a.in_slope`, the input planes and `Lin` (valid input columns) are what it reads of the arguments.
+template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, bool MRF, int RING = 3>
+__device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int t0, const int mt0, const int b, const int Lin, uint4* __restrict__ xs,
+                                                  floatx16 (&acc)[MB][NB]) {
   static_assert(CH == 32 || CH == 64, "staged chunk: 32 or 64 channels");
   constexpr int NT = 64 * WM * WN;
   constexpr int T_T = 32 * NB * WN;  // time columns per workgroup
@@ -101,19 +109,12 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   constexpr int S = SPC * K;         // steps per chunk: tap-major, the chunk's slabs per tap
   constexpr int AD = F16_ADIST, BD = F16_BDIST;
   static_assert(BD >= 1 && BD <= S && AD >= 1, "pipeline depths");
+  static_assert(RING >= 1 && RING <= 3, "ring depth");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave % WM;
   const int wn = wave / WM;
-  const int t0 = tile_x * T_T;
-  const int mt0 = (tile_y * WM + wm) * MB;
-
-  const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
-  const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
-  const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;
-  if (t0 >= n_len) return;  // uniform per workgroup
 
   const uint4* xb = a.x + (long long)b * a.x_bs;
   const uint4* xb2 = MRF ? a.x2 + (long long)b * a.x_bs : nullptr;
@@ -129,7 +130,8 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   // activated, one ds_write_b128.  THREE buffers: chunk c + 2 is requested at the start of chunk c's MFMA phase and written at
   // its end, in front of the ONE barrier of the chunk — which publishes it a whole chunk before its first read, so the B
   // fragments of the next chunk's first steps are read across the chunk boundary and the matrix stream never drains at a seam
-  // (rb_conv.h's ring, for this tile).  Loads / stores past the last chunk simply run (clamped addresses, a buffer nobody reads).
+  // (rb_conv.h's ring, for this tile).  Chunks past the last one are not staged (wave-uniform guards: a 32-channel conv has ONE
+  // chunk, and staging two more that nobody reads tripled its load and VALU work).
   auto gload = [&](int chunk, uint4 (&pre)[MRF ? 3 : 1][NU]) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -170,7 +172,6 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
     }
   };
 
-  floatx16 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -212,8 +213,10 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) Af[d][mb] = wq[mb][a_off(d)];
   lstore(0, 0, pre);
-  gload(1, pre);
-  lstore(1, 1, pre);
+  if (RING > 1 && nchunks > 1) {
+    gload(1, pre);
+    lstore(1, 1, pre);
+  }
   __syncthreads();
 #pragma unroll
   for (int d = 0; d < BD; ++d) bread(0, d, Bf[d]);
@@ -221,8 +224,9 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   constexpr int NMF = MB * NB;  // MFMAs per step
   int buf = 0;                  // ring buffer of the running chunk
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
-    gload(chunk + 2, pre);
+    const int buf1 = buf == RING - 1 ? 0 : buf + 1, buf2 = RING < 3 ? 0 : (buf1 == 2 ? 0 : buf1 + 1);
+    const bool more = RING == 3 && chunk + 2 < nchunks;
+    if (more) gload(chunk + 2, pre);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < S; ++st) {
@@ -255,10 +259,31 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) Bf[d][nb] = Bf[d + 1][nb];
     }
-    lstore(buf2, chunk + 2, pre);
-    __syncthreads();
+    if (more) lstore(buf2, chunk + 2, pre);
+    if (chunk + 1 < nchunks) __syncthreads();
     buf = buf1;
   }
+}
+
+template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int EPI, bool MRF, int RING = 3>
+__device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile_x, const int tile_y, const int b, uint4* __restrict__ xs) {
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_UPSAMPLE, "f16 tile epilogues");
+  constexpr int T_T = 32 * NB * WN;  // time columns per workgroup
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+  const int t0 = tile_x * T_T;
+  const int mt0 = (tile_y * WM + wm) * MB;
+
+  const int Lin = a.in_len ? a.in_len[b] * a.in_mul : a.in_const;
+  const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
+  const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;
+  if (t0 >= n_len) return;  // uniform per workgroup
+
+  floatx16 acc[MB][NB];
+  conv_f16_mainloop<K, MB, NB, WM, WN, HALO, CH, MRF, RING>(a, t0, mt0, b, Lin, xs, acc);
 
   // ---- epilogue: a lane holds, per 32 x 32 block, column l & 31 and the rows 8 j + 4 (l >> 5) + (0 .. 3), j = 0 .. 3
   const int col = lane & 31;
@@ -336,9 +361,9 @@ __device__ __forceinline__ int conv_f16_n_len(const HConvArgs& a, int b) {
   return a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
 }
 
-template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int EPI, bool MRF>
-__global__ __launch_bounds__(64 * WM * WN) void conv_f16_kernel(const HConvArgs a) {
-  __shared__ uint4 xs[conv_f16_lds_units<NB, WN, HALO, CH>()];
+template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int EPI, bool MRF, int RING = 3>
+__global__ __launch_bounds__(64 * WM * WN, F16_MIN_WAVES) void conv_f16_kernel(const HConvArgs a) {
+  __shared__ uint4 xs[conv_f16_lds_units<NB, WN, HALO, CH, RING>()];
   int tile_x, tile_y;
   int gx = gridDim.x;
   const int lin = blockIdx.x + blockIdx.y * gridDim.x;
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_f16_kernel(const HConvArgs 
     if (lin >= gx * (int)gridDim.y) return;
   }
   xcd_tile_lin(lin, gx, gridDim.y, tile_x, tile_y, a.rows_major);
-  conv_f16_tile<K, MB, NB, WM, WN, HALO, CH, EPI, MRF>(a, tile_x, tile_y, blockIdx.z, xs);
+  conv_f16_tile<K, MB, NB, WM, WN, HALO, CH, EPI, MRF, RING>(a, tile_x, tile_y, blockIdx.z, xs);
 }
 
 // The three MRF chains' same-geometry convs in ONE launch (conv_group_kernel's layout: members longest first, group sizes
@@ -357,9 +382,9 @@ struct HConvGroupArgs {
   int gx[3], gy[3];
   int off[4];
 };
-template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int CH>
-__global__ __launch_bounds__(64 * WM * WN) void conv_f16_group_kernel(const HConvGroupArgs g) {
-  constexpr int L0 = conv_f16_lds_units<NB, WN, H0, CH>(), L1 = conv_f16_lds_units<NB, WN, H1, CH>(), L2 = conv_f16_lds_units<NB, WN, H2, CH>();
+template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int CH, int RING = 3>
+__global__ __launch_bounds__(64 * WM * WN, F16_MIN_WAVES) void conv_f16_group_kernel(const HConvGroupArgs g) {
+  constexpr int L0 = conv_f16_lds_units<NB, WN, H0, CH, RING>(), L1 = conv_f16_lds_units<NB, WN, H1, CH, RING>(), L2 = conv_f16_lds_units<NB, WN, H2, CH, RING>();
   __shared__ uint4 xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];
   const int lin = blockIdx.x;
   const int b = blockIdx.z;
@@ -370,19 +395,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_f16_group_kernel(const HCon
     const int gx = ragged ? row_tiles(conv_f16_n_len<K0, EPI_LINEAR>(g.c[0], b), T_T) : g.gx[0];
     if (lin >= gx * g.gy[0]) return;
     xcd_tile_lin(lin, gx, g.gy[0], tx, ty);
-    conv_f16_tile<K0, MB, NB, WM, WN, H0, CH, EPI_LINEAR, false>(g.c[0], tx, ty, b, xs);
+    conv_f16_tile<K0, MB, NB, WM, WN, H0, CH, EPI_LINEAR, false, RING>(g.c[0], tx, ty, b, xs);
   } else if (lin < g.off[2]) {
     const int l = lin - g.off[1];
     const int gx = ragged ? row_tiles(conv_f16_n_len<K1, EPI_LINEAR>(g.c[1], b), T_T) : g.gx[1];
     if (l >= gx * g.gy[1]) return;
     xcd_tile_lin(l, gx, g.gy[1], tx, ty);
-    conv_f16_tile<K1, MB, NB, WM, WN, H1, CH, EPI_LINEAR, false>(g.c[1], tx, ty, b, xs);
+    conv_f16_tile<K1, MB, NB, WM, WN, H1, CH, EPI_LINEAR, false, RING>(g.c[1], tx, ty, b, xs);
   } else {
     const int l = lin - g.off[2];
     const int gx = ragged ? row_tiles(conv_f16_n_len<K2, EPI_LINEAR>(g.c[2], b), T_T) : g.gx[2];
     if (l >= gx * g.gy[2]) return;
     xcd_tile_lin(l, gx, g.gy[2], tx, ty);
-    conv_f16_tile<K2, MB, NB, WM, WN, H2, CH, EPI_LINEAR, false>(g.c[2], tx, ty, b, xs);
+    conv_f16_tile<K2, MB, NB, WM, WN, H2, CH, EPI_LINEAR, false, RING>(g.c[2], tx, ty, b, xs);
   }
 }
 

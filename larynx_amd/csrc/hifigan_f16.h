@@ -79,20 +79,22 @@ static void fix_h(HConvW& c, const uint16_t* arenaH, const float* arena) {
 }
 
 // ------------------------------------------------------------------ tiles
-// Three tile shapes, chosen by the conv's output rows (all 256 threads, 32-channel staged chunks):
-//   WIDE : 2 x 2 waves of 64 rows x 64 columns — 128 rows x 128 columns per workgroup   (rows >= 128)
-//   MID  : 1 x 4 waves of 64 x 64              —  64 rows x 256 columns                 (rows 33 .. 127)
-//   SLIM : 1 x 4 waves of 32 x 64              —  32 rows x 256 columns                 (rows <= 32)
+// Three tile shapes (all 256 threads, 32-channel staged chunks), chosen by the conv's output rows and input channels:
+//   WIDE : 2 x 2 waves of 64 rows x 64 columns — 128 rows x 128 columns per workgroup, the three-chunk ring (any Cin)
+//   MID  : 1 x 4 waves of 64 x 64              —  64 rows x 256 columns, Cin <= 64: both chunks staged in the prologue
+//   SLIM : 1 x 4 waves of 32 x 64              —  32 rows x 256 columns, Cin <= 32: the one chunk
 enum HTile { HT_WIDE = 0, HT_MID, HT_SLIM };
-static int h_tile_for(int rows) { return rows >= 128 ? HT_WIDE : rows > 32 ? HT_MID : HT_SLIM; }
+static int h_tile_for(int rows, int Cin) { return (rows <= 32 && Cin <= 32) ? HT_SLIM : (rows < 128 && Cin <= 64) ? HT_MID : HT_WIDE; }
 static void h_tile_dims(int t, int& trows, int& tcols) {
   trows = t == HT_WIDE ? 128 : t == HT_MID ? 64 : 32;
   tcols = t == HT_WIDE ? 128 : 256;
 }
+// template arguments MB, NB, WM, WN (then HALO ..., the chunk size) and the ring depth of each shape
 #define H_TILE_PARAMS_WIDE 2, 2, 2, 2
 #define H_TILE_PARAMS_MID 2, 2, 1, 4
 #define H_TILE_PARAMS_SLIM 1, 2, 1, 4
 constexpr int H_CH = 32;
+constexpr int H_RING_WIDE = 3, H_RING_MID = 2, H_RING_SLIM = 1;
 
 struct HPlan {
   HConvArgs a;
@@ -107,9 +109,9 @@ template <int K, int EPI, bool MRF>
 static int launch_f16_k(const HPlan& p, hipStream_t s) {
   constexpr int HALO = ConvHalo<K>::v;
   switch (p.tile) {
-    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_WIDE, HALO, H_CH, EPI, MRF>), p.grid, dim3(256), 0, s, p.a); return 0;
-    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_MID, HALO, H_CH, EPI, MRF>), p.grid, dim3(256), 0, s, p.a); return 0;
-    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_SLIM, HALO, H_CH, EPI, MRF>), p.grid, dim3(256), 0, s, p.a); return 0;
+    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_WIDE, HALO, H_CH, EPI, MRF, H_RING_WIDE>), p.grid, dim3(256), 0, s, p.a); return 0;
+    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_MID, HALO, H_CH, EPI, MRF, H_RING_MID>), p.grid, dim3(256), 0, s, p.a); return 0;
+    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_kernel<K, H_TILE_PARAMS_SLIM, HALO, H_CH, EPI, MRF, H_RING_SLIM>), p.grid, dim3(256), 0, s, p.a); return 0;
   }
   return fail(MI355TTS_ERR_INVALID, "internal: fp16 tile %d", p.tile);
 }
@@ -131,9 +133,9 @@ template <int K0, int K1, int K2>
 static int launch_f16_group_k(int tile, dim3 grid, const HConvGroupArgs& g, hipStream_t s) {
   constexpr int H0 = ConvHalo<K0>::v, H1 = ConvHalo<K1>::v, H2 = ConvHalo<K2>::v;
   switch (tile) {
-    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_WIDE, H0, H1, H2, H_CH>), grid, dim3(256), 0, s, g); return 0;
-    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_MID, H0, H1, H2, H_CH>), grid, dim3(256), 0, s, g); return 0;
-    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_SLIM, H0, H1, H2, H_CH>), grid, dim3(256), 0, s, g); return 0;
+    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_WIDE, H0, H1, H2, H_CH, H_RING_WIDE>), grid, dim3(256), 0, s, g); return 0;
+    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_MID, H0, H1, H2, H_CH, H_RING_MID>), grid, dim3(256), 0, s, g); return 0;
+    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_SLIM, H0, H1, H2, H_CH, H_RING_SLIM>), grid, dim3(256), 0, s, g); return 0;
   }
   return fail(MI355TTS_ERR_INVALID, "internal: fp16 tile %d", tile);
 }
@@ -168,6 +170,55 @@ static int run_group_f16(mi355tts_ctx* ctx, Worker* w, const HPlan* p, int n, in
   return k1173 ? launch_f16_group_k<11, 7, 3>(p[0].tile, grid, g, s) : launch_f16_group_k<7, 5, 3>(p[0].tile, grid, g, s);
 }
 
+// ---- fused ResBlock1 steps (pair_f16.h): conv1 + conv2 of a dilation step of the three chains in ONE launch.  A workgroup owns
+// all channels of its columns, so the tile is chosen by the channel count: C <= 32 SLIM, C <= 64 MID, C <= 128 WIDE.
+struct HPairPlan {
+  HPairArgs a;
+  int K = 0;
+  double flop = 0;
+};
+static int h_pair_tile(int C) { return C <= 32 ? HT_SLIM : C <= 64 ? HT_MID : C <= 128 ? HT_WIDE : -1; }
+template <int K0, int K1, int K2>
+static int launch_pair_group_k(int tile, dim3 grid, const HPairGroupArgs& g, hipStream_t s) {
+  constexpr int H0 = ConvHalo<K0>::v, H1 = ConvHalo<K1>::v, H2 = ConvHalo<K2>::v;
+  switch (tile) {
+    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_WIDE, H0, H1, H2, H_CH, H_RING_WIDE>), grid, dim3(256), 0, s, g); return 0;
+    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_MID, H0, H1, H2, H_CH, H_RING_MID>), grid, dim3(256), 0, s, g); return 0;
+    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_SLIM, H0, H1, H2, H_CH, H_RING_SLIM>), grid, dim3(256), 0, s, g); return 0;
+  }
+  return fail(MI355TTS_ERR_INVALID, "internal: fp16 pair tile %d", tile);
+}
+// Returns 0 = launched, 1 = not covered (the caller runs conv1 and conv2 as two grouped launches), < 0 = error.
+static int run_pair_group_f16(mi355tts_ctx* ctx, Worker* w, const HPairPlan* p, int n, int C, int B, int Lmax, hipStream_t s) {
+  if (n != 3) return 1;
+  const int tile = h_pair_tile(C);
+  if (tile < 0) return 1;
+  int ord[3] = {0, 1, 2};
+  std::sort(ord, ord + 3, [&](int x, int y) { return p[x].K > p[y].K; });
+  if (!(p[ord[0]].K == 11 && p[ord[1]].K == 7 && p[ord[2]].K == 3)) return 1;
+  int tr, tc;
+  h_tile_dims(tile, tr, tc);
+  HPairGroupArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.n = 3;
+  int off = 0;
+  double flop = 0;
+  for (int m = 0; m < 3; ++m) {
+    const HPairPlan& q = p[ord[m]];
+    const int to = tc - (q.K - 1);
+    g.p[m] = q.a;
+    g.gx[m] = (Lmax + to - 1) / to;
+    g.off[m] = off;
+    off += (g.gx[m] + 7) & ~7;
+    flop += q.flop;
+  }
+  g.off[3] = off;
+  ProfScope ps(ctx, w, KC_RESBLOCK, flop, s);
+  kn_hit(ctx, KN_PAIR_F16_GROUP);
+  g_last_sub = C;
+  return launch_pair_group_k<11, 7, 3>(tile, dim3(off, 1, B), g, s);
+}
+
 // lengths: one row with a host-known length takes it as a launch constant (no dependent load in every workgroup's prologue)
 static void h_set_lengths(HConvArgs& a, const int* d_frames, int host_len, int in_mul, int out_mul) {
   if (host_len >= 0) {
@@ -192,7 +243,7 @@ static HPlan plan_f16(const HConvW& c, HConvArgs a, int epi, int B, int n_max, d
   p.a = a;
   p.K = c.K;
   p.epi = epi;
-  p.tile = h_tile_for(c.rows);
+  p.tile = h_tile_for(c.rows, c.Cin);
   int tr, tc;
   h_tile_dims(p.tile, tr, tc);
   p.gx = (n_max + tc - 1) / tc;
@@ -307,8 +358,10 @@ static int hifigan_body_f16(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const m
       h_set_lengths(a, d_frames, voc_host_len, mul, mul);
       return a;
     };
+    const bool use_pair = h.resblock_type == 1 && ctx->rb_pair.load() && ctx->mrf_group.load();
     for (int d = 0; d < nd; ++d) {
       HPlan c1[3], c2[3];
+      HPairPlan pp[3];
       uint4* dst[3];
       for (int j = 0; j < nk; ++j) {
         const HResConv& rc = hm->h_rb[i][j][d];
@@ -320,12 +373,41 @@ static int hifigan_body_f16(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const m
           // consumer is conv2, which would apply it on load
           c1[j] = plan_f16(rc.c1, conv_args(rin[j], tb[j], nullptr, K, dil, 0.1f, 0.1f), EPI_LINEAR, B, Lout, flop);
           c2[j] = plan_f16(rc.c2, conv_args(tb[j], dst[j], rin[j], K, 1, 1.0f, 1.0f), EPI_LINEAR, B, Lout, flop);
+          HPairArgs& a = pp[j].a;
+          std::memset(&a, 0, sizeof(a));
+          a.x = rin[j];
+          a.y = dst[j];
+          a.bs = bs;
+          a.ld = ldo;
+          if (voc_host_len >= 0) {
+            a.len = nullptr;
+            a.len_const = voc_host_len * mul;
+          } else {
+            a.len = d_frames;
+          }
+          a.len_mul = mul;
+          a.w1 = rc.c1.w;
+          a.b1 = rc.c1.bias;
+          a.nslab1 = rc.c1.nslab;
+          a.w2 = rc.c2.w;
+          a.b2 = rc.c2.bias;
+          a.nslab2 = rc.c2.nslab;
+          a.C = ch;
+          a.dil = dil;
+          a.slope = 0.1f;
+          pp[j].K = K;
+          pp[j].flop = 2.0 * flop;
         } else {
           // ResBlock2.forward (models.py:136-141): x = c(lrelu(x)) + x
           c1[j] = plan_f16(rc.c1, conv_args(rin[j], dst[j], rin[j], K, dil, 0.1f, 1.0f), EPI_LINEAR, B, Lout, flop);
         }
       }
-      for (int pass = 0; pass < (h.resblock_type == 1 ? 2 : 1); ++pass) {
+      int fused = 1;
+      if (use_pair) {
+        fused = run_pair_group_f16(ctx, w, pp, nk, ch, B, Lout, s);
+        if (fused < 0) return fused;
+      }
+      for (int pass = 0; fused != 0 && pass < (h.resblock_type == 1 ? 2 : 1); ++pass) {
         const HPlan* pl = pass ? c2 : c1;
         int rc = ctx->mrf_group.load() ? run_group_f16(ctx, w, pl, nk, B, s) : 1;
         if (rc < 0) return rc;

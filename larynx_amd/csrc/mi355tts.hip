@@ -40,6 +40,7 @@
 #include "voc_out.h"
 #include "small_kernels.h"
 #include "conv_f16.h"
+#include "pair_f16.h"
 #include "weights_pack.h"
 
 using namespace mi355tts;

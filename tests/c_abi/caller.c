@@ -148,7 +148,21 @@ int main(int argc, char** argv) {
   }
   CHECK(mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_BF16X3));
   CHECK(mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_F32));
-  CHECK(mi355tts_model_set_precision(ctx, glow, MI355TTS_PRECISION_BF16X3));
+  /* GlowTTS computes in f32 whatever is asked: a reduced-precision request is reported as a no-op, F32 returns 0 */
+  if (mi355tts_model_set_precision(ctx, glow, MI355TTS_PRECISION_BF16X3) != MI355TTS_PRECISION_NOOP ||
+      mi355tts_model_set_precision(ctx, glow, MI355TTS_PRECISION_F16) != MI355TTS_PRECISION_NOOP) { fprintf(stderr, "GlowTTS precision request not reported as a no-op\n"); return 1; }
+  CHECK(mi355tts_model_set_precision(ctx, glow, MI355TTS_PRECISION_F32));
+  { /* the native fp16 vocoder: accepted where its tiles cover the geometry, refused with a reason where not */
+    int rc16 = mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_F16);
+    if (rc16 != 0 && rc16 != MI355TTS_ERR_INVALID) { fprintf(stderr, "fp16 request: unexpected status %d\n", rc16); return 1; }
+    if (rc16 == 0) {
+      CHECK(mi355tts_hifigan_infer(ctx, voc, mel, 0.0f, wav, pcm, wav_ld, 0u));
+      for (int b = 0; b < B; ++b)
+        for (int i = frames[b] * hop; i < wav_ld; ++i)
+          if (wav[(size_t)b * wav_ld + i] != 0.0f || pcm[(size_t)b * wav_ld + i] != 0) { fprintf(stderr, "fp16: tail not zero\n"); return 1; }
+      CHECK(mi355tts_model_set_precision(ctx, voc, MI355TTS_PRECISION_F32));
+    }
+  }
   if (mi355tts_model_set_precision(ctx, voc, 99) == 0) { fprintf(stderr, "unknown precision accepted\n"); return 1; }
   if (mi355tts_broadcast_weights(ctx, NULL, 0, NULL, 0, NULL) == 0) { fprintf(stderr, "null communicator accepted\n"); return 1; }
   printf("frames %d %d mel_sum %.6e wav_sum %.6e pcm_sum %ld\n", (int)frames[0], (int)frames[1], mel_sum, wav_sum, pcm_sum);

@@ -1,8 +1,9 @@
 """The native fp16 vocoder (MI355TTS_PRECISION_F16: csrc/conv_f16.h + csrc/hifigan_f16.h) on the CPU emulator, against the numpy
 oracle in f32.  The mode trades accuracy for speed as the reference's `.half()` does (larynx/hifi_gan.py:96-97), so the bar is
 a half-precision error band — an index slip (a wrong tap, octet, phase or chain) is an O(1) error, three orders above it.
-Covers: both ResBlock types, 2 and 3 chains (single and grouped launches, both grouped tap sets), the three tile shapes
-(128 / 64 / <= 32 rows), ragged batches with per-row tails, the int16 tail, and the mode's error reporting."""
+Covers: both ResBlock types, 2 and 3 chains (single and grouped launches, both grouped tap sets), the fused conv1 + conv2
+launches (pair_f16.h) at 128 / 64 / 16 / 8 channels and their two-launch form, the three tile shapes (128 / 64 / <= 32 rows),
+ragged batches with per-row tails, the int16 tail, and the mode's error reporting."""
 import numpy as np
 import pytest
 
@@ -20,7 +21,10 @@ RB2_THREE = HP.HifiGanHParams(
     resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)),
     num_mels=16,
 )
+# stages of 128 and 64 channels with the shipped (3, 7, 11) x (1, 3, 5) chains: the fused-pair kernel's WIDE and MID tiles
+PAIR_WIDE = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256, num_mels=16)
 CASES = {
+    "pairs_128_64": PAIR_WIDE,
     "rb1_two_chains": HP.TINY_HIFIGAN,
     "rb2_two_chains": HP.TINY_HIFIGAN_RB2,
     "wide_and_mid_tiles": HP.TINY_HIFIGAN_PAIR,  # 64- and 32-channel stages, conv_pre 128 rows, upsamplers of 128 / 64 rows
@@ -41,7 +45,7 @@ def test_f16_vocoder_matches_the_oracle_within_half_precision(emu_engine, case):
     try:
         assert emu_engine.set_precision(v, ffi.PRECISION_F16) == 0
         rng = np.random.default_rng(11)
-        frames = np.array([41, 9, 300 if case == "grouped_11_7_3" else 23], np.int32)
+        frames = np.array([41, 9, 300 if case == "grouped_11_7_3" else 70 if case == "pairs_128_64" else 23], np.int32)
         Fm = int(frames.max())
         melin = (rng.standard_normal((3, hp.num_mels, Fm)) * 2).astype(np.float32)
         mb = emu_engine.mel_from_numpy(melin, frames)
@@ -49,7 +53,9 @@ def test_f16_vocoder_matches_the_oracle_within_half_precision(emu_engine, case):
         f32, i16 = emu_engine.hifigan_infer(v, mb)
         counts = emu_engine.kernel_counts()
         assert counts.get("conv_f16_kernel", 0) > 0 and counts.get("post_f16_kernel", 0) == 1 and counts.get("pack_octets_kernel", 0) == 1
-        assert (counts.get("conv_f16_group_kernel", 0) > 0) == case.startswith("grouped")
+        fused = case in ("grouped_11_7_3", "pairs_128_64")  # ResBlock1 chains with the (3, 7, 11) taps: one launch per dilation step
+        assert (counts.get("conv_f16_group_kernel", 0) > 0) == (case == "grouped_7_5_3")
+        assert counts.get("pair_f16_group_kernel", 0) == (2 * 3 if fused else 0)
         for name in ("conv_mfma_kernel", "rb_conv_kernel", "conv_bf16_kernel", "mrf_small_kernel", "mrf8_kernel", "post_conv_kernel"):
             assert counts.get(name, 0) == 0, name  # every layer honours the switch
         hop = hp.hop
@@ -71,6 +77,33 @@ def test_f16_vocoder_matches_the_oracle_within_half_precision(emu_engine, case):
         f32x, _ = emu_engine.hifigan_infer(v, solo)
         ref1 = hifi_gan_np.hifigan_infer(sd, hp, melin[1, :, : frames[1]])
         assert np.sqrt(np.mean((f32x[0, :n1] - ref1) ** 2)) < 1e-5
+    finally:
+        emu_engine.unload(v)
+
+
+@pytest.mark.parametrize("which", ["narrow", "wide"])
+def test_f16_fused_pairs_against_their_two_launch_form(emu_engine, which):
+    """pair_f16.h keeps conv1's tile in LDS: same products, same f32 accumulation order, same roundings as conv1 -> plane ->
+    conv2 — the fused launch must give the two-launch form's bits."""
+    hp = HP.TINY_HIFIGAN_NARROW if which == "narrow" else PAIR_WIDE
+    sd = synthetic.make_hifigan_state_dict(hp, seed=9)
+    v = emu_engine.load_hifigan(hp, sd)
+    try:
+        emu_engine.set_precision(v, ffi.PRECISION_F16)
+        rng = np.random.default_rng(4)
+        frames = np.array([150 if which == "narrow" else 45, 7], np.int32)
+        melin = (rng.standard_normal((2, hp.num_mels, int(frames.max()))) * 2).astype(np.float32)
+        mb = emu_engine.mel_from_numpy(melin, frames)
+        a, _ = emu_engine.hifigan_infer(v, mb)
+        emu_engine.set_option("rb_pair", 0)
+        try:
+            emu_engine.profile_reset()
+            b, _ = emu_engine.hifigan_infer(v, mb)
+            counts = emu_engine.kernel_counts()
+            assert counts.get("pair_f16_group_kernel", 0) == 0 and counts.get("conv_f16_group_kernel", 0) == 2 * 3 * 2
+        finally:
+            emu_engine.set_option("rb_pair", 1)
+        np.testing.assert_array_equal(a, b)
     finally:
         emu_engine.unload(v)
 

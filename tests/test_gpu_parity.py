@@ -658,8 +658,12 @@ def test_f16_mode_against_the_reference(gpu_engine, name):
     again, _ = gpu_engine.hifigan_infer(v, mb)
     assert np.array_equal(exact, again)
     vh = c["voc_hp"]
-    per_step = 2 if vh.resblock == "1" else 1
-    assert counts.get("conv_f16_group_kernel", 0) == len(vh.upsample_rates) * len(vh.resblock_dilation_sizes[0]) * per_step
+    steps = len(vh.upsample_rates) * len(vh.resblock_dilation_sizes[0])
+    if vh.resblock == "1":  # one fused conv1 + conv2 launch per dilation step (pair_f16.h) up to 128 channels, two grouped launches above
+        wide = sum(1 for i in range(len(vh.upsample_rates)) if vh.stage_channels(i) > 128) * len(vh.resblock_dilation_sizes[0])
+        assert counts.get("pair_f16_group_kernel", 0) == steps - wide and counts.get("conv_f16_group_kernel", 0) == 2 * wide
+    else:
+        assert counts.get("conv_f16_group_kernel", 0) == steps and counts.get("pair_f16_group_kernel", 0) == 0
     assert counts.get("conv_f16_kernel", 0) == 1 + len(vh.upsample_rates) and counts.get("post_f16_kernel", 0) == 1
     for k in ("conv_mfma_kernel", "conv_mfma_kernel.m128", "rb_group_kernel", "rb_group_kernel.snake", "rb_pair_group_kernel", "conv_bf16_group_kernel",
               "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "post_conv_kernel"):
