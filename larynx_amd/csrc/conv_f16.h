@@ -95,7 +95,7 @@ constexpr int conv_f16_lds_units() {
 // The main loop of a tile: acc[mb][nb] += W (m-tiles mt0 .. mt0 + MB) x X over all input channels and taps, for the T_T computed
 // columns whose first one is implicit-GEMM column t0 (input column t0 - a.pad at tap 0).  `a.w`, `a.nslab`, `a.Cin`, `a.dil`, `a.pad`,
 // `a.in_slope`, the input planes and `Lin` (valid input columns) are what it reads of the arguments.
-template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, bool MRF, int RING = 3>
+template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, bool MRF, int RING = 3, int AD = F16_ADIST>
 __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int t0, const int mt0, const int b, const int Lin, uint4* __restrict__ xs,
                                                   floatx16 (&acc)[MB][NB]) {
   static_assert(CH == 32 || CH == 64, "staged chunk: 32 or 64 channels");
@@ -107,13 +107,13 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   constexpr int NU = (BUF + NT - 1) / NT;
   constexpr int SPC = CH / 16;       // slabs per chunk
   constexpr int S = SPC * K;         // steps per chunk: tap-major, the chunk's slabs per tap
-  constexpr int AD = F16_ADIST, BD = F16_BDIST;
+  constexpr int BD = F16_BDIST;
   static_assert(BD >= 1 && BD <= S && AD >= 1, "pipeline depths");
   static_assert(RING >= 1 && RING <= 3, "ring depth");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave / WM;
 
   const uint4* xb = a.x + (long long)b * a.x_bs;
@@ -180,16 +180,28 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   uint4 pre[MRF ? 3 : 1][NU];
 
-  // A stream of m-tile mt: uint4 index ((mt * nslab + slab) * K + k) * 64 + lane
+  // A stream of m-tile mt: uint4 index ((mt * nslab + slab) * K + k) * 64 + lane.  The base of an m-tile is wave-uniform (a
+  // scalar pointer), the lane's share a constant 32-bit offset, and the step's offset = its chunk's base + a COMPILE-TIME
+  // constant (the steps of a chunk are unrolled): no division, no 64-bit vector adds in the loop (the first form derived the
+  // offset from the global step number, 21 scalar instructions a step in front of the step's first MFMA).  Steps past the
+  // last chunk re-read the last chunk (chunk index clamped): loaded, never used.
   const uint4* wq[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) wq[mb] = a.w + (long long)(mt0 + mb) * a.nslab * K * 64 + lane;
-  const int last_step = nchunks * S - 1;
-  auto a_off = [&](int g) -> int {  // uint4 offset of global step g (clamped at the end: a harmless re-load)
-    g = g < last_step ? g : last_step;
-    const int ch = g / S, st = g - ch * S;
-    const int k = st / SPC, s = st - k * SPC;
-    return ((ch * SPC + s) * K + k) * 64;
+  for (int mb = 0; mb < MB; ++mb) wq[mb] = a.w + (long long)(mt0 + mb) * a.nslab * K * 64;
+  constexpr int CHW = SPC * K * 64;  // uint4 units of one chunk's fragments of one m-tile
+  static_assert(AD <= 2 * S, "weight look-ahead spans at most two chunk seams");
+  auto chunk_base = [&](int c) -> int { return (c < nchunks ? c : nchunks - 1) * CHW; };
+  // offset of step t (0 <= t < 3 S, compile-time after unrolling) counted from the running chunk, whose and whose two
+  // successors' bases are cb[0 .. 2]
+  auto a_off = [&](const int (&cb)[3], int t) -> int {
+    const int ci = t / S, tt = t - ci * S;
+    const int k = tt / SPC, sl = tt - k * SPC;
+    return cb[ci] + (sl * K + k) * 64;
+  };
+  // scalar base + the lane's constant 32-bit byte offset: global_load's saddr form, no vector address arithmetic
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto aload = [&](const uint4* base, int soff) -> uint4 {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + soff) + lane16);
   };
   // Operand pipeline of a wave (registers): weight fragments AD steps ahead of the MFMAs that use them (an L2 hit is ~700
   // cycles, a step of MB x NB MFMAs 128-256: with two steps ahead a lone wave per SIMD ran at 0.2 of its matrix pipe), LDS
@@ -208,10 +220,13 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   };
 
   gload(0, pre);
+  {
+    const int cb[3] = {chunk_base(0), chunk_base(1), chunk_base(2)};
 #pragma unroll
-  for (int d = 0; d < AD; ++d)
+    for (int d = 0; d < AD; ++d)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) Af[d][mb] = wq[mb][a_off(d)];
+      for (int mb = 0; mb < MB; ++mb) Af[d][mb] = aload(wq[mb], a_off(cb, d));
+  }
   lstore(0, 0, pre);
   if (RING > 1 && nchunks > 1) {
     gload(1, pre);
@@ -227,13 +242,14 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
     const int buf1 = buf == RING - 1 ? 0 : buf + 1, buf2 = RING < 3 ? 0 : (buf1 == 2 ? 0 : buf1 + 1);
     const bool more = RING == 3 && chunk + 2 < nchunks;
     if (more) gload(chunk + 2, pre);
+    const int cb[3] = {chunk_base(chunk), chunk_base(chunk + 1), chunk_base(chunk + 2)};
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < S; ++st) {
       {
-        const int off = a_off(chunk * S + st + AD);
+        const int off = a_off(cb, st + AD);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) Af[AD][mb] = wq[mb][off];
+        for (int mb = 0; mb < MB; ++mb) Af[AD][mb] = aload(wq[mb], off);
       }
       if (st + BD < S) bread(buf, st + BD, Bf[BD]);
       else bread(buf1, st + BD - S, Bf[BD]);  // across the seam: the next chunk's tile was published a chunk ago
@@ -271,7 +287,7 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   constexpr int T_T = 32 * NB * WN;  // time columns per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM;
   const int wn = wave / WM;
   const int t0 = tile_x * T_T;

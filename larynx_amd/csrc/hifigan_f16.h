@@ -182,9 +182,9 @@ template <int K0, int K1, int K2>
 static int launch_pair_group_k(int tile, dim3 grid, const HPairGroupArgs& g, hipStream_t s) {
   constexpr int H0 = ConvHalo<K0>::v, H1 = ConvHalo<K1>::v, H2 = ConvHalo<K2>::v;
   switch (tile) {
-    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_WIDE, H0, H1, H2, H_CH, H_RING_WIDE>), grid, dim3(256), 0, s, g); return 0;
-    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_MID, H0, H1, H2, H_CH, H_RING_MID>), grid, dim3(256), 0, s, g); return 0;
-    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_SLIM, H0, H1, H2, H_CH, H_RING_SLIM>), grid, dim3(256), 0, s, g); return 0;
+    case HT_WIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_WIDE, H0, H1, H2, H_CH, H_RING_WIDE, 3>), grid, dim3(256), 0, s, g); return 0;
+    case HT_MID: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_MID, H0, H1, H2, H_CH, H_RING_MID, 3>), grid, dim3(256), 0, s, g); return 0;
+    case HT_SLIM: hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<K0, K1, K2, H_TILE_PARAMS_SLIM, H0, H1, H2, H_CH, H_RING_SLIM, 4>), grid, dim3(256), 0, s, g); return 0;
   }
   return fail(MI355TTS_ERR_INVALID, "internal: fp16 pair tile %d", tile);
 }

@@ -33,10 +33,17 @@ struct HPairArgs {
 };
 
 constexpr int PAIR_TPAD = 16;  // padding columns of the intermediate tile (>= K - 1)
+#ifndef PAIR_F16_ADIST
+#define PAIR_F16_ADIST 3  // weight fragments in flight (steps): three or four waves per SIMD cover the rest of an L2 hit between them
+#endif
 
+// conv1's staging ring and the intermediate tile SHARE the workgroup's LDS: the ring is dead once every wave has left pass 1's
+// main loop (one barrier), and the tile is written only after it — half the LDS of keeping both, twice the workgroups per CU
 template <int K, int NB, int WN, int HALO, int CH, int RING>
 constexpr int pair_f16_lds_units(int rows) {
-  return conv_f16_lds_units<NB, WN, HALO, CH, RING>() + (rows / 8) * (32 * NB * WN + PAIR_TPAD);
+  constexpr int ring = conv_f16_lds_units<NB, WN, HALO, CH, RING>();
+  const int tile = (rows / 8) * (32 * NB * WN + PAIR_TPAD);
+  return ring > tile ? ring : tile;
 }
 
 template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int RING>
@@ -44,14 +51,14 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
   constexpr int T = 32 * NB * WN;
   constexpr int TO = T - (K - 1);
   constexpr int TW = T + PAIR_TPAD;
-  constexpr int AD = F16_ADIST, BD = F16_BDIST;
+  constexpr int AD = PAIR_F16_ADIST, BD = F16_BDIST;
   static_assert(K - 1 <= PAIR_TPAD, "intermediate tile padding");
-  uint4* const xs = lds;                                        // conv1's staging ring
-  uint4* const ts = lds + conv_f16_lds_units<NB, WN, HALO, CH, RING>();  // intermediate tile [rows / 8][TW]
+  uint4* const xs = lds;  // conv1's staging ring
+  uint4* const ts = lds;  // intermediate tile [rows / 8][TW], over the ring once pass 1's main loop is done
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM;
   const int wn = wave / WM;
   const int mt0 = wm * MB;
@@ -76,7 +83,8 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
   a1.pad = P2 * a.dil;
   a1.in_slope = a.slope;
   floatx16 acc[MB][NB];
-  conv_f16_mainloop<K, MB, NB, WM, WN, HALO, CH, false, RING>(a1, c1, mt0, b, L, xs, acc);
+  conv_f16_mainloop<K, MB, NB, WM, WN, HALO, CH, false, RING, AD>(a1, c1, mt0, b, L, xs, acc);
+  __syncthreads();  // every wave has read its last B fragments: the ring's LDS becomes the intermediate tile
 
   const int col = lane & 31;
   const int rsub = 4 * (lane >> 5);
@@ -114,15 +122,21 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
   // accumulation order — and with it every bit of the result — is that of the two-launch form.
   const int nch2 = rows_t >> 5;
   constexpr int S2 = 2 * K;
-  const int last2 = nch2 * S2 - 1;
   const uint4* wq[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) wq[mb] = a.w2 + (long long)(mt0 + mb) * a.nslab2 * K * 64 + lane;
-  auto a_off = [&](int g) -> int {  // uint4 offset of global step g (clamped at the end: a harmless re-load)
-    g = g < last2 ? g : last2;
-    const int ch = g / S2, st = g - ch * S2;
-    const int k = st >> 1, sl = st & 1;
-    return ((2 * ch + sl) * K + k) * 64;
+  for (int mb = 0; mb < MB; ++mb) wq[mb] = a.w2 + (long long)(mt0 + mb) * a.nslab2 * K * 64;  // wave-uniform bases
+  constexpr int CHW2 = 2 * K * 64;
+  static_assert(AD <= 2 * S2, "weight look-ahead spans at most two chunk seams");
+  auto chunk_base = [&](int c) -> int { return (c < nch2 ? c : nch2 - 1) * CHW2; };
+  auto a_off = [&](const int (&cb)[3], int t) -> int {  // step t (compile-time) counted from the running chunk: see conv_f16_mainloop
+    const int ci = t / S2, tt = t - ci * S2;
+    const int k = tt >> 1, sl = tt & 1;
+    return cb[ci] + (sl * K + k) * 64;
+  };
+  // scalar base + the lane's constant 32-bit byte offset: global_load's saddr form, no vector address arithmetic
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto aload = [&](const uint4* base, int soff) -> uint4 {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + soff) + lane16);
   };
   const int colb = wn * (NB * 32) + (lane & 31);
   const int ohalf = lane >> 5;
@@ -136,10 +150,13 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
   static_assert(BD < S2, "pass 2 looks at most one chunk ahead");
   uint4 Af[AD + 1][MB];
   uint4 Bf[BD + 1][NB];
+  {
+    const int cb[3] = {chunk_base(0), chunk_base(1), chunk_base(2)};
 #pragma unroll
-  for (int d = 0; d < AD; ++d)
+    for (int d = 0; d < AD; ++d)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) Af[d][mb] = wq[mb][a_off(d)];
+      for (int mb = 0; mb < MB; ++mb) Af[d][mb] = aload(wq[mb], a_off(cb, d));
+  }
 #pragma unroll
   for (int d = 0; d < BD; ++d) bread(0, d, Bf[d]);
 #pragma unroll
@@ -150,12 +167,13 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   constexpr int NMF = MB * NB;
   for (int ch = 0; ch < nch2; ++ch) {
+    const int cb[3] = {chunk_base(ch), chunk_base(ch + 1), chunk_base(ch + 2)};
 #pragma unroll
     for (int st = 0; st < S2; ++st) {
       {
-        const int off = a_off(ch * S2 + st + AD);
+        const int off = a_off(cb, st + AD);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) Af[AD][mb] = wq[mb][off];
+        for (int mb = 0; mb < MB; ++mb) Af[AD][mb] = aload(wq[mb], off);
       }
       if (st + BD < S2) bread(ch, st + BD, Bf[BD]);
       else bread(ch + 1, st + BD - S2, Bf[BD]);
@@ -225,8 +243,8 @@ struct HPairGroupArgs {
   int off[4];  // first workgroup of each member, off[3] = grid size
   int n;       // members (1 .. 3)
 };
-template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int CH, int RING>
-__global__ __launch_bounds__(64 * WM * WN, F16_MIN_WAVES) void pair_f16_group_kernel(const HPairGroupArgs g) {
+template <int K0, int K1, int K2, int MB, int NB, int WM, int WN, int H0, int H1, int H2, int CH, int RING, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void pair_f16_group_kernel(const HPairGroupArgs g) {
   constexpr int ROWS = 32 * MB * WM;
   constexpr int L0 = pair_f16_lds_units<K0, NB, WN, H0, CH, RING>(ROWS), L1 = pair_f16_lds_units<K1, NB, WN, H1, CH, RING>(ROWS),
                 L2 = pair_f16_lds_units<K2, NB, WN, H2, CH, RING>(ROWS);

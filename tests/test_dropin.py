@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import larynx_amd
+from larynx_amd import ffi
 from larynx_amd import hparams as HP
 from larynx_amd import synthetic
 from larynx_amd.audio import ljspeech_audio_settings
@@ -192,8 +193,10 @@ def test_unsupported_requests_raise(emu_library, voice_dirs):
 
 def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
     """`half=True` (the reference's registry default for voices, larynx/__init__.py:297; `.half()` at
-    larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97): GlowTTS keeps computing in f32, the vocoder moves its
-    ResBlock convs to the split-bf16 kernels — same interface, audio within a few LSB of the exact mode."""
+    larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97): GlowTTS keeps computing in f32 (the library reports the switch as a
+    no-op there), the vocoder runs its native fp16 mode (csrc/conv_f16.h) — same interface, audio within a half-precision
+    band of the exact mode (the reference's own generator under .half() moves the int16 samples by 40 - 85 LSB on the golden
+    set: tests/golden/*.npz, ref_half_i16)."""
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
     gdir, vdir = tmp_path / "half-glow_tts", tmp_path / "half_hifi_gan"
@@ -209,7 +212,8 @@ def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
         tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, half=half, library_path=emu_library)
         voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, half=half, library_path=emu_library)
         assert voc.half is half
+        assert voc.precision == (ffi.PRECISION_F16 if half else ffi.PRECISION_F32)
         out[half] = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
     assert out[True].shape == out[False].shape and out[True].dtype == np.int16
     d = np.abs(out[True].astype(np.int32) - out[False].astype(np.int32))
-    assert d.max() <= 8 and not np.array_equal(out[True], out[False])
+    assert d.max() <= 128 and not np.array_equal(out[True], out[False])
