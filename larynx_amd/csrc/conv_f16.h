@@ -68,6 +68,14 @@ __device__ __forceinline__ floatx16 mfma_f16(const uint4& a, const uint4& b, flo
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
 
+// lanes 32 .. 63 of `a` change places with lanes 0 .. 31 of `b` (v_permlane32_swap_b32), both dwords
+__device__ __forceinline__ void swap32(uint2& a, uint2& b) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+  a = uint2{r0[0], r1[0]};
+  b = uint2{r0[1], r1[1]};
+}
+
 // leaky ReLU of 8 packed halves, 0 <= slope <= 1: max(v, v * slope)
 __device__ __forceinline__ uint4 lrelu_h8(const uint4& v, _Float16 slope) {
   const half8 h = __builtin_bit_cast(half8, v);
@@ -76,7 +84,10 @@ __device__ __forceinline__ uint4 lrelu_h8(const uint4& v, _Float16 slope) {
 }
 
 #ifndef F16_ADIST
-#define F16_ADIST 6  // weight fragments in flight ahead of the MFMAs that use them (steps)
+#define F16_ADIST 4  // weight fragments in flight ahead of the MFMAs that use them (steps)
+#endif
+#ifndef F16_ABLATE
+#define F16_ABLATE 0  // probe builds only (tools/probe/f16_bench.hip): 1 = no epilogue, 2 = no MFMAs, 4 = no weight loads, 8 = no LDS reads, 16 = no staging
 #endif
 #ifndef F16_MIN_WAVES
 #define F16_MIN_WAVES 1  // __launch_bounds__' second argument: waves per SIMD the register allocation must leave room for
@@ -92,9 +103,11 @@ constexpr int conv_f16_lds_units() {
   return RING * (CH / 8) * (32 * NB * WN + HALO);
 }
 
-// The main loop of a tile: acc[mb][nb] += W (m-tiles mt0 .. mt0 + MB) x X over all input channels and taps, for the T_T computed
-// columns whose first one is implicit-GEMM column t0 (input column t0 - a.pad at tap 0).  `a.w`, `a.nslab`, `a.Cin`, `a.dil`, `a.pad`,
-// `a.in_slope`, the input planes and `Lin` (valid input columns) are what it reads of the arguments.
+// The main loop of a tile: acc[mb][nb] = bias + W (m-tiles mt0 .. mt0 + MB) x X over all input channels and taps, for the T_T
+// computed columns whose first one is implicit-GEMM column t0 (input column t0 - a.pad at tap 0).  `a.w`, `a.bias`, `a.nslab`,
+// `a.Cin`, `a.dil`, `a.pad`, `a.in_slope`, the input planes and `Lin` (valid input columns) are what it reads of the arguments.
+// The accumulators START at the bias (virtual-row order, padded to whole m-tiles by pack_conv_f16): its loads — four 16-byte
+// loads per m-tile — fly with the prologue's staging loads instead of standing between the last MFMA and the stores.
 template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, bool MRF, int RING = 3, int AD = F16_ADIST>
 __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int t0, const int mt0, const int b, const int Lin, uint4* __restrict__ xs,
                                                   floatx16 (&acc)[MB][NB]) {
@@ -173,11 +186,20 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   };
 
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {
+    float4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mb) * 32 + 8 * j + 4 * (lane >> 5));
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        acc[mb][nb][4 * j + 0] = b4[j].x;
+        acc[mb][nb][4 * j + 1] = b4[j].y;
+        acc[mb][nb][4 * j + 2] = b4[j].z;
+        acc[mb][nb][4 * j + 3] = b4[j].w;
+      }
+  }
   uint4 pre[MRF ? 3 : 1][NU];
 
   // A stream of m-tile mt: uint4 index ((mt * nslab + slab) * K + k) * 64 + lane.  The base of an m-tile is wave-uniform (a
@@ -240,7 +262,7 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   int buf = 0;                  // ring buffer of the running chunk
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf1 = buf == RING - 1 ? 0 : buf + 1, buf2 = RING < 3 ? 0 : (buf1 == 2 ? 0 : buf1 + 1);
-    const bool more = RING == 3 && chunk + 2 < nchunks;
+    const bool more = RING == 3 && chunk + 2 < nchunks && !(F16_ABLATE & 16);
     if (more) gload(chunk + 2, pre);
     const int cb[3] = {chunk_base(chunk), chunk_base(chunk + 1), chunk_base(chunk + 2)};
     __builtin_amdgcn_sched_barrier(0);
@@ -249,14 +271,18 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
       {
         const int off = a_off(cb, st + AD);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) Af[AD][mb] = aload(wq[mb], off);
+        for (int mb = 0; mb < MB; ++mb)
+          if (!(F16_ABLATE & 4)) Af[AD][mb] = aload(wq[mb], off);
       }
-      if (st + BD < S) bread(buf, st + BD, Bf[BD]);
-      else bread(buf1, st + BD - S, Bf[BD]);  // across the seam: the next chunk's tile was published a chunk ago
+      if (!(F16_ABLATE & 8)) {
+        if (st + BD < S) bread(buf, st + BD, Bf[BD]);
+        else bread(buf1, st + BD - S, Bf[BD]);  // across the seam: the next chunk's tile was published a chunk ago
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_f16(Af[0][mb], Bf[0][nb], acc[mb][nb]);
+        for (int nb = 0; nb < NB; ++nb)
+          if (!(F16_ABLATE & 2)) acc[mb][nb] = mfma_f16(Af[0][mb], Bf[0][nb], acc[mb][nb]);
       // issue order: the MB weight loads behind the first MFMAs, then the NB LDS reads (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
@@ -298,71 +324,83 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;
   if (t0 >= n_len) return;  // uniform per workgroup
 
+  // the residual is requested BEFORE the main loop (clamped addresses: nothing behind a branch) and consumed after it
+  const int col = lane & 31;
+  const int hi = lane >> 5;
+  uint4 resv[MB][NB][2];
+  if (EPI == EPI_LINEAR && a.res) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int orow = (mt0 + mb) * 32 + 16 * jp + 8 * hi;
+          const int q = t0 + (wn * NB + nb) * 32 + col;
+          const bool ok = orow < a.rows && q < n_len;
+          resv[mb][nb][jp] = a.res[(long long)b * a.y_bs + (long long)(ok ? (orow >> 3) : 0) * a.y_ld + (ok ? q : 0)];
+        }
+  }
   floatx16 acc[MB][NB];
   conv_f16_mainloop<K, MB, NB, WM, WN, HALO, CH, MRF, RING>(a, t0, mt0, b, Lin, xs, acc);
+  if (F16_ABLATE & 1) {  // probe builds: keep the accumulators alive, store nothing
+    float t = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) t += acc[mb][nb][0] + acc[mb][nb][7];
+    if (t == 1.2345e30f) a.y[0] = uint4{0u, 0u, 0u, 0u};
+    return;
+  }
 
-  // ---- epilogue: a lane holds, per 32 x 32 block, column l & 31 and the rows 8 j + 4 (l >> 5) + (0 .. 3), j = 0 .. 3
-  const int col = lane & 31;
-  const int rsub = 4 * (lane >> 5);
+  // ---- epilogue: a lane holds, per 32 x 32 block, column l & 31 and the rows 8 j + 4 (l >> 5) + (0 .. 3), j = 0 .. 3: HALF an
+  // octet unit per j.  Lanes l and l + 32 trade halves (swap32): of the octets j0 = 2 jp and j1 = 2 jp + 1 the lower lane ends up
+  // with all of j0, the upper lane with all of j1 — residual loads and result stores are whole 16-byte units, half as many
+  // memory instructions as 8 bytes per lane (the epilogue's cost is their issue, not their bytes).
   const bool out_act = a.out_slope != 1.0f;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float bb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (mt0 + mb) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
-      bb[r] = (a.bias && row < a.rows) ? a.bias[row] : 0.f;
-    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int q = t0 + (wn * NB + nb) * 32 + col;
-      if (q >= n_len) continue;
-      if constexpr (EPI == EPI_UPSAMPLE) {
+      if (q >= n_len) continue;  // (lanes l and l + 32 share their column: both stay or both go)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row0 = (mt0 + mb) * 32 + 8 * j + rsub;
-          if (row0 >= a.rows) continue;
-          const int r = row0 / a.cout, co0 = row0 - r * a.cout;
+      for (int jp = 0; jp < 2; ++jp) {
+        const int orow = (mt0 + mb) * 32 + 16 * jp + 8 * hi;  // first row of the octet this lane loads / stores
+        bool ok = orow < a.rows;
+        long long off;
+        if constexpr (EPI == EPI_UPSAMPLE) {
+          const int r = orow / a.cout, co0 = orow - r * a.cout;
           const int n = q * a.up + r - a.up_pad;
-          if (n < 0 || n >= Lout) continue;
+          ok = ok && n >= 0 && n < Lout;
+          off = (long long)b * a.y_bs + (long long)(co0 >> 3) * a.y_ld + n;
+        } else {
+          off = (long long)b * a.y_bs + (long long)(orow >> 3) * a.y_ld + q;
+        }
+        uint2 ra = {0u, 0u}, rb = {0u, 0u};  // residuals of j0 and j1 in the accumulators' layout
+        if (EPI == EPI_LINEAR && a.res) {
+          const uint4 rv = resv[mb][nb][jp];
+          ra = uint2{rv.x, rv.y};
+          rb = uint2{rv.z, rv.w};
+          swap32(ra, rb);
+        }
+        uint2 u[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * jp + jj;
+          const half4 rh = __builtin_bit_cast(half4, jj ? rb : ra);
           half4 hv;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[mb][nb][4 * j + e] + bb[4 * j + e]);
-          uint2* dst = reinterpret_cast<uint2*>(a.y + (long long)b * a.y_bs + (long long)(co0 >> 3) * a.y_ld + n) + ((co0 >> 2) & 1);
-          *dst = __builtin_bit_cast(uint2, hv);
-        }
-      } else {
-        uint2 rv[4];
-        if (a.res) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row0 = (mt0 + mb) * 32 + 8 * j + rsub;
-            const int rr = row0 < a.rows ? row0 : 0;
-            rv[j] = reinterpret_cast<const uint2*>(a.res + (long long)b * a.y_bs + (long long)(rr >> 3) * a.y_ld + q)[(rr >> 2) & 1];
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[mb][nb][4 * j + e];
+            if (EPI == EPI_LINEAR && a.res) v += (float)rh[e];
+            if (EPI == EPI_LINEAR && out_act) v = v > 0.f ? v : v * a.out_slope;
+            hv[e] = (_Float16)v;
           }
+          u[jj] = __builtin_bit_cast(uint2, hv);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row0 = (mt0 + mb) * 32 + 8 * j + rsub;
-          if (row0 >= a.rows) continue;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * j + e] + bb[4 * j + e];
-          if (a.res) {
-            const half4 rh = __builtin_bit_cast(half4, rv[j]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rh[e];
-          }
-          if (out_act) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.out_slope;
-          }
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
-          uint2* dst = reinterpret_cast<uint2*>(a.y + (long long)b * a.y_bs + (long long)(row0 >> 3) * a.y_ld + q) + ((row0 >> 2) & 1);
-          *dst = __builtin_bit_cast(uint2, hv);
-        }
+        swap32(u[0], u[1]);
+        if (ok) a.y[off] = uint4{u[0].x, u[0].y, u[1].x, u[1].y};
       }
     }
   }

@@ -34,7 +34,7 @@ struct HPairArgs {
 
 constexpr int PAIR_TPAD = 16;  // padding columns of the intermediate tile (>= K - 1)
 #ifndef PAIR_F16_ADIST
-#define PAIR_F16_ADIST 3  // weight fragments in flight (steps): three or four waves per SIMD cover the rest of an L2 hit between them
+#define PAIR_F16_ADIST 2  // weight fragments in flight (steps): three or four waves per SIMD cover the rest of an L2 hit between them
 #endif
 
 // conv1's staging ring and the intermediate tile SHARE the workgroup's LDS: the ring is dead once every wave has left pass 1's
@@ -77,6 +77,7 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
   a1.x_bs = a.bs;
   a1.x_ld = a.ld;
   a1.w = a.w1;
+  a1.bias = a.b1;
   a1.nslab = a.nslab1;
   a1.Cin = a.C;
   a1.dil = a.dil;
@@ -96,9 +97,6 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
     for (int j = 0; j < 4; ++j) {
       const int row0 = (mt0 + mb) * 32 + 8 * j + rsub;
       if (row0 >= rows_t) continue;
-      float bb[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bb[e] = row0 + e < a.C ? a.b1[row0 + e] : 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int jc = (wn * NB + nb) * 32 + col;
@@ -107,7 +105,7 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
         half4 hv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = acc[mb][nb][4 * j + e] + bb[e];
+          float v = acc[mb][nb][4 * j + e];
           v = v > 0.f ? v : v * a.slope;
           hv[e] = (_Float16)(in ? v : 0.f);
         }
@@ -116,6 +114,24 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
     }
   }
   __syncthreads();
+
+  // the residual (the tile's own input columns: L2-warm) is requested HERE, a whole pass ahead of the epilogue that adds it
+  const uint4* xb = a.x + (long long)b * a.bs;
+  uint4* yb = a.y + (long long)b * a.bs;
+  const int hi = lane >> 5;
+  uint4 resv[MB][NB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int orow = (mt0 + mb) * 32 + 16 * jp + 8 * hi;
+        const int c = t0 + (wn * NB + nb) * 32 + col;
+        const bool ok = orow < a.C && c < L;
+        const long long off = (long long)(ok ? (orow >> 3) : 0) * a.ld + (ok ? c : 0);
+        resv[mb][nb][jp] = xb[off];  // clamped address: nothing behind a branch
+      }
 
   // ---- pass 2: conv2 (dilation 1) from the intermediate tile; weights streamed as in pass 1, no staging, no barriers.
   // Step order = conv_f16_mainloop's at CH = 32 (per 32-channel chunk: tap-major, the chunk's two slabs per tap), so the
@@ -160,11 +176,20 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
 #pragma unroll
   for (int d = 0; d < BD; ++d) bread(0, d, Bf[d]);
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {  // accumulators start at conv2's bias (see conv_f16_mainloop)
+    float4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(a.b2 + (mt0 + mb) * 32 + 8 * j + 4 * (lane >> 5));
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        acc[mb][nb][4 * j + 0] = b4[j].x;
+        acc[mb][nb][4 * j + 1] = b4[j].y;
+        acc[mb][nb][4 * j + 2] = b4[j].z;
+        acc[mb][nb][4 * j + 3] = b4[j].w;
+      }
+  }
   constexpr int NMF = MB * NB;
   for (int ch = 0; ch < nch2; ++ch) {
     const int cb[3] = {chunk_base(ch), chunk_base(ch + 1), chunk_base(ch + 2)};
@@ -200,29 +225,34 @@ __device__ __forceinline__ void pair_f16_tile(const HPairArgs& a, const int tile
     }
   }
 
-  // ---- conv2 epilogue: y = acc + bias + x (residual in f32, one rounding)
-  const uint4* xb = a.x + (long long)b * a.bs;
-  uint4* yb = a.y + (long long)b * a.bs;
+  // ---- conv2 epilogue: y = acc + bias + x (residual in f32, one rounding); whole 16-byte units per lane (see conv_f16_tile)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row0 = (mt0 + mb) * 32 + 8 * j + rsub;
-      if (row0 >= a.C) continue;
-      float bb[4];
+    for (int nb = 0; nb < NB; ++nb) {
+      const int q = (wn * NB + nb) * 32 + col;
+      const int c = t0 + q;
+      if (q >= TO || c >= L) continue;  // (lanes l and l + 32 share their column)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bb[e] = a.b2[row0 + e];
+      for (int jp = 0; jp < 2; ++jp) {
+        const int orow = (mt0 + mb) * 32 + 16 * jp + 8 * hi;
+        const bool ok = orow < a.C;
+        const long long off = (long long)(orow >> 3) * a.ld + c;
+        const uint4 rv = resv[mb][nb][jp];
+        uint2 ra = uint2{rv.x, rv.y}, rb = uint2{rv.z, rv.w};
+        swap32(ra, rb);
+        uint2 u[2];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int q = (wn * NB + nb) * 32 + col;
-        const int c = t0 + q;
-        if (q >= TO || c >= L) continue;
-        const long long off = (long long)(row0 >> 3) * a.ld + c;
-        const half4 rh = __builtin_bit_cast(half4, reinterpret_cast<const uint2*>(xb + off)[(row0 >> 2) & 1]);
-        half4 hv;
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * jp + jj;
+          const half4 rh = __builtin_bit_cast(half4, jj ? rb : ra);
+          half4 hv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[mb][nb][4 * j + e] + bb[e] + (float)rh[e]);
-        reinterpret_cast<uint2*>(yb + off)[(row0 >> 2) & 1] = __builtin_bit_cast(uint2, hv);
+          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[mb][nb][4 * j + e] + (float)rh[e]);
+          u[jj] = __builtin_bit_cast(uint2, hv);
+        }
+        swap32(u[0], u[1]);
+        if (ok) yb[off] = uint4{u[0].x, u[0].y, u[1].x, u[1].y};
       }
     }
   }

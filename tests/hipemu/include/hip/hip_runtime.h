@@ -258,6 +258,13 @@ inline f32x16 mfma_f32_32x32x16_f16(f16x8_emu a, f16x8_emu b, f32x16 c) {
   return c;
 }
 
+// v_permlane32_swap_b32 (gfx950): lanes 32 .. 63 of `old` change places with lanes 0 .. 31 of `src`; returns {old', src'}
+struct u32x2_emu {
+  uint32_t v[2];
+  uint32_t operator[](int i) const { return v[i]; }
+};
+u32x2_emu permlane32_swap(uint32_t old_v, uint32_t src_v);
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur()->tid)
@@ -291,6 +298,17 @@ template <typename T> static inline T __shfl_up(T v, unsigned delta, int width =
 #define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, cbsz, abid, blgp) hipemu::mfma_f32_4x4x1((a), (b), (c), (cbsz), (abid))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_f32_32x32x16_f16((a), (b), (c))
+namespace hipemu {
+inline u32x2_emu permlane32_swap(uint32_t old_v, uint32_t src_v) {
+  const int l = cur()->lane;
+  const uint32_t old_o = shfl_generic(old_v, l ^ 32), src_o = shfl_generic(src_v, l ^ 32);
+  u32x2_emu r;
+  r.v[0] = l < 32 ? old_v : src_o;  // upper lanes of old' = lower lanes of src
+  r.v[1] = l < 32 ? old_o : src_v;  // lower lanes of src' = upper lanes of old
+  return r;
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu::permlane32_swap((a), (b))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 // lanes are fibers here: a wave's lock step (an LDS write another lane of the SAME wave then reads) needs a real rendezvous

@@ -217,3 +217,39 @@ def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
     assert out[True].shape == out[False].shape and out[True].dtype == np.int16
     d = np.abs(out[True].astype(np.int32) - out[False].astype(np.int32))
     assert d.max() <= 128 and not np.array_equal(out[True], out[False])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_full_size_voice_through_sentence_task_on_the_device(tmp_path, half):
+    """BASELINE config 2 through the reference-shaped classes at FULL size: a voice directory holding the ljspeech GlowTTS +
+    hifi_gan 'high' checkpoints (seeded synthetic weights — the goldens' own), `HipGlowTextToSpeech` / `HipHiFiGanVocoder` built
+    by the registry functions, `larynx_amd.sentence_task` as `/root/reference/larynx/__init__.py:229-257` runs it, against the
+    reference-made golden of the bench utterance (`ljspeech_high_S120`): int16 within 1 LSB in the exact mode; with `half=True`
+    (the registry's default for voices, larynx/__init__.py:297) within the reference's OWN .half() deviation on that case."""
+    from tests.golden_util import load_case
+
+    c = load_case("ljspeech_high_S120")
+    gdir, vdir = tmp_path / "ljspeech-glow_tts", tmp_path / "hifi_gan_universal_large"
+    gdir.mkdir()
+    vdir.mkdir()
+    cfg = c["glow_hp"].to_config()
+    cfg["audio"].update({k: v for k, v in vars(ljspeech_audio_settings()).items() if k != "mel_channels"})
+    (gdir / "config.json").write_text(json.dumps(cfg))
+    vcfg = c["voc_hp"].to_config()
+    vcfg["audio"] = {"num_mels": c["voc_hp"].num_mels}
+    (vdir / "config.json").write_text(json.dumps(vcfg))
+    np.savez(gdir / "generator.npz", **synthetic.make_glow_state_dict(c["glow_hp"], seed=1234))
+    np.savez(vdir / "generator.npz", **synthetic.make_hifigan_state_dict(c["voc_hp"], seed=1234))
+    tts = larynx_amd.load_tts_model(TextToSpeechType.GLOW_TTS, gdir, backend=InferenceBackend.HIP, half=half)
+    voc = larynx_amd.load_vocoder_model(VocoderType.HIFI_GAN, vdir, backend=InferenceBackend.HIP, half=half)
+    assert voc.precision == (ffi.PRECISION_F16 if half else ffi.PRECISION_F32)
+    setattr(tts, "phoneme_to_id", {"_": 0})
+    setattr(tts, "audio_settings", ljspeech_audio_settings())
+    settings = {"noise_scale": float(c["noise_scale"]), "length_scale": float(c["length_scale"]), "noise": c["noise"]}
+    audio = larynx_amd.sentence_task("golden", [int(i) for i in c["ids"]], getattr(tts, "audio_settings"), tts, settings, voc, None)
+    assert audio.dtype == np.int16 and audio.shape == c["wav_i16"].shape
+    d = int(np.abs(audio.astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
+    assert d <= (1.5 * int(c["ref_half_i16"]) if half else 1), d
+    if half:
+        assert d > 1  # the fp16 mode really ran

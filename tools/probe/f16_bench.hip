@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../larynx_amd/csrc/conv_f16.h"
+#include "../../larynx_amd/csrc/pair_f16.h"
 #include "../../larynx_amd/csrc/weights_pack.h"
 
 using namespace mi355tts;
@@ -38,7 +38,7 @@ static void launch(int cfg, dim3& grid_out, const HConvArgs& a, int n_len, hipSt
   CFG(2, 2, 2, 1, 4, 64)  // 64 x 256
   CFG(3, 1, 2, 1, 4, 32)  // 32 x 256
   CFG(4, 2, 2, 2, 2, 32)
-  CFG(5, 2, 4, 1, 4, 64)  // 64 x 512
+  CFG(5, 2, 4, 1, 4, 32)  // 64 x 512
   CFG(6, 1, 4, 1, 4, 32)  // 32 x 512
 #undef CFG
   std::printf("unknown cfg %d\n", cfg);
@@ -94,7 +94,7 @@ static int run_group(int C, int dil, int L, int cfg, int iters) {
     else if (cfg == 2) launch_group<2, 2, 1, 4, 64>(g, grid);
     else if (cfg == 3) launch_group<1, 2, 1, 4, 32>(g, grid);
     else if (cfg == 4) launch_group<2, 2, 2, 2, 32>(g, grid);
-    else if (cfg == 5) launch_group<2, 4, 1, 4, 64>(g, grid);
+    else if (cfg == 5) launch_group<2, 4, 1, 4, 32>(g, grid);
     else launch_group<1, 4, 1, 4, 32>(g, grid);
   };
   for (int i = 0; i < 3; ++i) go();
@@ -113,6 +113,83 @@ static int run_group(int C, int dil, int L, int cfg, int iters) {
   return 0;
 }
 
+// fused conv1 + conv2 steps of the three MRF members (pair_f16.h), timing only: f16_bench C C -1 dil L tile iters   (tile 0 WIDE, 1 MID, 2 SLIM)
+#ifndef PROBE_PAIR_MINW
+#define PROBE_PAIR_MINW 3
+#endif
+static int run_pair_group(int C, int dil, int L, int tile, int iters) {
+  const int Ks[3] = {11, 7, 3};
+  const int noct = C / 8, ld = L + 3;
+  uint4 *dx, *dy[3], *dw[3][2];
+  float* db;
+  HC(hipMalloc(&dx, (size_t)noct * ld * 16));
+  {
+    std::vector<uint16_t> hx((size_t)noct * ld * 8);
+    uint32_t st = 777u;
+    for (auto& v : hx) {
+      st = st * 1664525u + 1013904223u;
+      v = f16_rne(((st >> 8) * (1.0f / 16777216.0f)) * 4.0f - 2.0f);
+    }
+    HC(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  }
+  HC(hipMalloc(&db, 4 * 1024));
+  HC(hipMemset(db, 0, 4 * 1024));
+  HPairGroupArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.n = 3;
+  const int tcols = tile == 0 ? 128 : 256;
+  int off = 0;
+  double flop = 0;
+  for (int m = 0; m < 3; ++m) {
+    const int K = Ks[m];
+    std::vector<uint16_t> w((size_t)4 * (4 * ((C + 63) / 64)) * K * 64 * 8 + 4096);
+    {
+      uint32_t st = 4242u + m;
+      for (auto& v : w) {
+        st = st * 1664525u + 1013904223u;
+        v = f16_rne((((st >> 8) * (1.0f / 16777216.0f)) * 2.0f - 1.0f) * 0.03f);
+      }
+    }
+    for (int c = 0; c < 2; ++c) {
+      HC(hipMalloc(&dw[m][c], w.size() * 2));
+      HC(hipMemcpy(dw[m][c], w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    }
+    HC(hipMalloc(&dy[m], (size_t)noct * ld * 16));
+    HPairArgs& a = g.p[m];
+    a.x = dx; a.y = dy[m]; a.bs = (long long)noct * ld; a.ld = ld; a.len_const = L;
+    a.w1 = dw[m][0]; a.b1 = db; a.nslab1 = 4 * ((C + 63) / 64);
+    a.w2 = dw[m][1]; a.b2 = db; a.nslab2 = a.nslab1;
+    a.C = C; a.dil = dil; a.slope = 0.1f;
+    const int to = tcols - (K - 1);
+    g.gx[m] = (L + to - 1) / to;
+    g.off[m] = off;
+    off += (g.gx[m] + 7) & ~7;
+    flop += 4.0 * C * C * K * (double)L;
+  }
+  g.off[3] = off;
+  const dim3 grid(off, 1, 1);
+  auto go = [&]() {
+    constexpr int H0 = ConvHalo<11>::v, H1 = ConvHalo<7>::v, H2 = ConvHalo<3>::v;
+    if (tile == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 2, 2, 2, H0, H1, H2, 32, 3, PROBE_PAIR_MINW>), grid, dim3(256), 0, nullptr, g);
+    else if (tile == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 2, 1, 4, H0, H1, H2, 32, 2, PROBE_PAIR_MINW>), grid, dim3(256), 0, nullptr, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 1, 2, 1, 4, H0, H1, H2, 32, 1, 4>), grid, dim3(256), 0, nullptr, g);
+  };
+  for (int i = 0; i < 3; ++i) go();
+  hipEvent_t e0, e1;
+  HC(hipEventCreate(&e0));
+  HC(hipEventCreate(&e1));
+  HC(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) go();
+  HC(hipEventRecord(e1, nullptr));
+  HC(hipEventSynchronize(e1));
+  float ms = 0;
+  HC(hipEventElapsedTime(&ms, e0, e1));
+  const double us = 1e3 * ms / iters;
+  std::printf("PAIR GROUP C %d dil %d L %d tile %d (%d workgroups): %.2f us per launch, %.1f TFLOP/s (%.3f of 2500)\n", C, dil, L, tile, off, us, flop / us * 1e-6,
+              flop / us * 1e-6 / 2500.0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 7) {
     std::printf("usage: f16_bench Cin Cout K dil L cfg [iters] [up]\n");
@@ -124,6 +201,7 @@ int main(int argc, char** argv) {
   const int up = argc > 8 ? std::atoi(argv[8]) : 0;
   const bool mrf = argc > 9 && std::atoi(argv[9]) != 0;
   if (K == 0) return run_group(Cin, dil, L, cfg, iters);
+  if (K < 0) return run_pair_group(Cin, dil, L, cfg, iters);
   uint32_t st = 12345u;
   auto rnd = [&]() {
     st = st * 1664525u + 1013904223u;
