@@ -456,6 +456,7 @@ def main():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE", help="mi355tts_set_option before anything runs (A/B of schedules)")
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
+    ap.add_argument("--tiny-half", action="store_true", help="with --tiny: run the half-mode (fp16) and split-bf16 legs too (they are skipped on the emulator by default)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
                     help="f32 = exact f32 MFMA everywhere (the graded parity mode); f16 = the `half` switch: the native fp16 vocoder "
                          "(fp16 planes, one fp16 MFMA per product); bf16x3 = split-bf16 ResBlock convs (3 x bf16 MFMA per product, f32 planes)")
@@ -808,7 +809,7 @@ def main():
     # exact f32 mode).  Same steps, same method, fewer repeats.  Next to it the split-bf16 mode (f32-class accuracy), in-flight only.
     half = None
     x3_flight = 0.0
-    if args.precision == "f32" and not args.tiny and not args.no_half_mode:
+    if args.precision == "f32" and (not args.tiny or args.tiny_half) and not args.no_half_mode:
         eng.set_precision(v, ffi.PRECISION_F16)
         run_steps(0, max(W, conc))
         step(W)

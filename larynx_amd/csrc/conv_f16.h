@@ -137,6 +137,7 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   const int c_first = t0 - a.pad;  // input column of staged column 0
   const int ld_last = a.x_ld - 1;
   const _Float16 slope = (_Float16)a.in_slope;
+  const _Float16 inv_div = (_Float16)(1.0f / (MRF ? a.in_div : 1.0f));
   const bool plain = a.in_slope == 1.0f;
 
   // ---- staging: unit u = (octet o, staged column c): one 16-byte load (clamped address: nothing behind a branch), masked,
@@ -173,11 +174,11 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
       const bool ok = col >= 0 && col < Lin && chunk * OCT + o < noct_in;
       uint4 v = pre[0][i];
       if constexpr (MRF) {
+        // the MRF average in packed halves, as the reference's half generator takes it (xs += resblock(x); x = xs / num_kernels
+        // on half tensors, hifi_gan/models.py:191-197): twelve packed operations per unit (f32 sums and a true division
+        // were sixty)
         const half8 h0 = __builtin_bit_cast(half8, v), h1 = __builtin_bit_cast(half8, pre[1][i]), h2 = __builtin_bit_cast(half8, pre[2][i]);
-        half8 r;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (_Float16)((((float)h0[e] + (float)h1[e]) + (float)h2[e]) / a.in_div);
-        v = __builtin_bit_cast(uint4, r);
+        v = __builtin_bit_cast(uint4, ((h0 + h1) + h2) * inv_div);
       }
       if (!plain) v = lrelu_h8(v, slope);
       if (!ok) v = uint4{0u, 0u, 0u, 0u};
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(256) void post_f16_kernel(const HPostArgs a) {
   const uint4* xb = a.x + (long long)b * a.x_bs;
   const uint4* xb2 = NPL > 1 ? a.x2 + (long long)b * a.x_bs : nullptr;
   const uint4* xb3 = NPL > 2 ? a.x3 + (long long)b * a.x_bs : nullptr;
+  const float inv_div = 1.0f / a.in_div;
   for (int u = tid; u < noct * XW; u += 256) {
     const int o = u / XW, c = u - o * XW;
     const int col = t0 - (K - 1) / 2 + c;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void post_f16_kernel(const HPostArgs a) {
       float v = (float)h0[e];
       if (NPL > 1) v += (float)h1[e];
       if (NPL > 2) v += (float)h2[e];
-      if (NPL > 1) v = v / a.in_div;
+      if (NPL > 1) v = v * inv_div;
       v = v > 0.f ? v : v * a.slope;
       xs[8 * o + e][c] = ok ? v : 0.f;
     }

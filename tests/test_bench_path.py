@@ -12,15 +12,34 @@ import pytest
 REPO = Path(__file__).resolve().parent.parent
 
 
-def _run(emu_library, gpus, utterances=7):
+def _run(emu_library, gpus, utterances=7, extra=()):
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--ids", "12",
            "--concurrency", "2", "--repeats", "2", "--config3-utterances", str(utterances), "--device", "cpu", "--library", str(emu_library),
-           "--tiny", "--no-cpu-baseline"]
+           "--tiny", "--no-cpu-baseline", *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=str(REPO))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout  # rank 0 prints ONE JSON line
     return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu_with_the_half_mode_legs(emu_library_path):
+    """The path the driver runs first (N = 1: no process group, no all_reduce), with the secondary legs the emulator runs skip by
+    default: `half_mode` (the native fp16 vocoder) and `bf16x3_mode`; and the shape of `roofline.by_kernel` (per kernel NAME and
+    launch sub-key: launches, average raw-event microseconds) that lets a driver record be compared kernel by kernel."""
+    out = _run(emu_library_path, 1, 5, extra=("--tiny-half",))
+    assert out["n_gpus"] == 1 and out["process_group"] is None and out["config"]["parallelism"] == "utterance-dp1"
+    assert out["value"] > 0 and abs(out["value"] - 3 / (out["ms_per_step"] * 3 / 1e3)) < 1e-6 * out["value"]
+    bk = out["roofline"]["by_kernel"]
+    assert set(bk) >= {"conv_mfma.hifigan_resblock", "conv_mfma.hifigan_upsample", "glow_top"}
+    for cls, rows in bk.items():
+        for name, r in rows.items():
+            assert "/" in name and r["launches"] > 0 and r["avg_us"] > 0 and r["total_ms"] > 0, (cls, name, r)
+    hm = out["half_mode"]
+    assert hm["utterances_per_sec"] > 0 and hm["ms_per_step"] > 0 and hm["latency_ms_single_stream"] > 0
+    assert hm["dtype"].startswith("f16") and hm["roofline"]["bound"] == "mfma" and hm["roofline"]["launches"] > 0
+    assert any(k.startswith("conv_f16") or k.startswith("pair_f16") for k in hm["roofline"]["by_kernel"]["conv_mfma.hifigan_resblock"])
+    assert out["bf16x3_mode"]["utterances_per_sec"] > 0
 
 
 @pytest.mark.parametrize("gpus,utterances", [(2, 7), (8, 19)])
