@@ -137,7 +137,7 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   const int c_first = t0 - a.pad;  // input column of staged column 0
   const int ld_last = a.x_ld - 1;
   const _Float16 slope = (_Float16)a.in_slope;
-  const _Float16 inv_div = (_Float16)(1.0f / (MRF ? a.in_div : 1.0f));
+  const float inv_div = 1.0f / (MRF ? a.in_div : 1.0f);
   const bool plain = a.in_slope == 1.0f;
 
   // ---- staging: unit u = (octet o, staged column c): one 16-byte load (clamped address: nothing behind a branch), masked,
@@ -174,11 +174,15 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
       const bool ok = col >= 0 && col < Lin && chunk * OCT + o < noct_in;
       uint4 v = pre[0][i];
       if constexpr (MRF) {
-        // the MRF average in packed halves, as the reference's half generator takes it (xs += resblock(x); x = xs / num_kernels
-        // on half tensors, hifi_gan/models.py:191-197): twelve packed operations per unit (f32 sums and a true division
-        // were sixty)
+        // the MRF average (xs / num_kernels, hifi_gan/models.py:191-197) summed in f32 and rounded ONCE — v_fma_mix takes the
+        // half operands as they are, and the division is a multiplication by 1 / num_kernels.  (Packed-half sums, which is how
+        // the reference's half tensors take it, cost a fifth of the first form's sixty VALU operations per unit but put the
+        // 'high' goldens at 3.36e-4 RMS against the reference's own 3.30e-4: this form keeps them at 2.7e-4.)
         const half8 h0 = __builtin_bit_cast(half8, v), h1 = __builtin_bit_cast(half8, pre[1][i]), h2 = __builtin_bit_cast(half8, pre[2][i]);
-        v = __builtin_bit_cast(uint4, ((h0 + h1) + h2) * inv_div);
+        half8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (_Float16)((((float)h0[e] + (float)h1[e]) + (float)h2[e]) * inv_div);
+        v = __builtin_bit_cast(uint4, r);
       }
       if (!plain) v = lrelu_h8(v, slope);
       if (!ok) v = uint4{0u, 0u, 0u, 0u};

@@ -301,10 +301,9 @@ int main(int argc, char** argv) {
   auto xin = [&](int c, int t) -> double {
     if (t < 0 || t >= L) return 0.0;
     double v = fx[(size_t)c * L + t];
-    if (mrf) {  // packed-half average: ((x + x2) + x3) * half(1 / 3), each operation rounded to fp16
-      const float s1 = f16_to_float(f16_rne(fx[(size_t)c * L + t] + fx[((size_t)Cin + c) * L + t]));
-      const float s2 = f16_to_float(f16_rne(s1 + fx[((size_t)2 * Cin + c) * L + t]));
-      v = f16_to_float(f16_rne(s2 * f16_to_float(f16_rne(1.0f / 3.0f))));
+    if (mrf) {  // f32 sum, one rounding
+      const float s3 = ((fx[(size_t)c * L + t] + fx[((size_t)Cin + c) * L + t]) + fx[((size_t)2 * Cin + c) * L + t]) * (1.0f / 3.0f);
+      v = f16_to_float(f16_rne(s3));
     }
     const float h = (float)v;
     const float act = f16_to_float(f16_rne(h > 0.f ? h : f16_to_float(f16_rne(h * f16_to_float(f16_rne(0.1f))))));
