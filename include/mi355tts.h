@@ -283,7 +283,8 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  *   "gate16", "glow_fuse", "mrf_small" (0/1, default 1) — the small-launch kernels of gate16.h / coltile.h / mrf_small.h
  *     (0 = the generic tiles);
  *   "rb_pair" (0/1, default 1) — the fused ResBlock steps of the 64- / 32-channel stages on the 4-wave tile without a k-split
- *     (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h);
+ *     (rb_pair.h; 0 = the 8-wave k-split tile of resblock_pair.h).  In the fp16 mode: conv1 + conv2 of a ResBlock1 step as ONE launch
+ *     (pair_f16.h; 0 = two launches — there the two forms give the SAME bits);
  *   "group_promote" (0/1, default 1) — at batch 1 the same-geometry ResBlock convs of a step that are too short for the 128-row
  *     tile's own threshold move to it when the round-robin deal of their (all resident) workgroups stays balanced: decided from
  *     the device's CU count and the launch geometry alone (0 = they keep the 64 x 32 k-split tile);

@@ -258,7 +258,7 @@ static HPlan plan_f16(const HConvW& c, HConvArgs a, int epi, int B, int n_max, d
 // same channels and row stride takes half of one.  Leaves the f32 waveform rows in `wav` ([B][Nld]) and, when asked, the
 // |max| of every 256-sample tile in `peak` (voc_out.h's wave_out_kernel reads both).
 static int hifigan_body_f16(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355tts_mel* mel, float* const* buf, float* wav, size_t Nld,
-                            float* peak, long long peak_ld, int voc_host_len, hipStream_t s) {
+                            float* peak, long long peak_ld, int voc_host_len, bool use_group, bool use_pairs, hipStream_t s) {
   const mi355tts_hifigan_hparams& h = hm->hp;
   const int B = mel->B, F = mel->max_frames;
   const int C0 = h.upsample_initial_channel, nk = h.num_kernels, nd = h.num_dilations;
@@ -358,7 +358,7 @@ static int hifigan_body_f16(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const m
       h_set_lengths(a, d_frames, voc_host_len, mul, mul);
       return a;
     };
-    const bool use_pair = h.resblock_type == 1 && ctx->rb_pair.load() && ctx->mrf_group.load();
+    const bool use_pair = h.resblock_type == 1 && use_pairs;  // (the options as the call saw them at its start)
     for (int d = 0; d < nd; ++d) {
       HPlan c1[3], c2[3];
       HPairPlan pp[3];
@@ -409,7 +409,7 @@ static int hifigan_body_f16(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const m
       }
       for (int pass = 0; fused != 0 && pass < (h.resblock_type == 1 ? 2 : 1); ++pass) {
         const HPlan* pl = pass ? c2 : c1;
-        int rc = ctx->mrf_group.load() ? run_group_f16(ctx, w, pl, nk, B, s) : 1;
+        int rc = use_group ? run_group_f16(ctx, w, pl, nk, B, s) : 1;
         if (rc < 0) return rc;
         if (rc == 1)
           for (int j = 0; j < nk; ++j) CHECK(run_plan_f16(ctx, w, pl[j], KC_RESBLOCK, s));

@@ -13,7 +13,8 @@ extern "C" int mi355tts_hifigan_hop(mi355tts_ctx* ctx, int vocoder) {
 
 static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
   std::lock_guard<std::mutex> lk(hm->bias_mu);
-  if (hm->bias_ready) return 0;
+  const int bi = hm->precision.load() == MI355TTS_PRECISION_F16 ? 1 : 0;
+  if (hm->bias_ready[bi]) return 0;
   const int M = hm->hp.num_mels, hop = hm->hop;
   const int zf = 88;  // the reference's all-zero mel has 88 frames (hifi_gan.py:187,198)
   const long long N = (long long)zf * hop;
@@ -45,8 +46,8 @@ static int ensure_denoiser_bias(mi355tts_ctx* ctx, HifiModel* hm, int vocoder) {
     if (bias) hipFree(bias);
     return rc;
   }
-  hm->bias_spec = bias;
-  hm->bias_ready = true;
+  hm->bias_spec[bi] = bias;
+  hm->bias_ready[bi] = true;
   return 0;
 }
 
@@ -281,7 +282,8 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
   if (f16) {
     if ((size_t)((mel->M + 7) / 8) * F * 16 > lay.plane * sizeof(float)) return fail(MI355TTS_ERR_INVALID, "internal: mel octets exceed a plane buffer");
     peak_parts_ready = any_i16 && !denoise;
-    CHECK(hifigan_body_f16(ctx, w, hm, mel, buf, wav, Nld, peak_parts_ready ? reinterpret_cast<float*>(peak) : nullptr, peak_ld, voc_host_len, s));
+    CHECK(hifigan_body_f16(ctx, w, hm, mel, buf, wav, Nld, peak_parts_ready ? reinterpret_cast<float*>(peak) : nullptr, peak_ld, voc_host_len,
+                           opt_group, opt_group && w->o_rb_pair, s));
   } else {
   // stage input: `cur[0]` alone, or the nk chain outputs cur[0..nk) still to be averaged
   float* cur[3] = {buf[0], nullptr, nullptr};
@@ -533,7 +535,7 @@ static int hifigan_run(mi355tts_ctx* ctx, Worker* w, HifiModel* hm, const mi355t
     ProfScope ps(ctx, w, KC_SMALL, 0);
     float* wav2 = (float*)(base + o_wav2);
     float* fbuf = (float*)(base + o_fbuf);
-    hipLaunchKernelGGL(stft_denoise_kernel, dim3(Tmax, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, hm->bias_spec,
+    hipLaunchKernelGGL(stft_denoise_kernel, dim3(Tmax, B), dim3(256), 0, s, wav, (long long)Nld, d_frames, hop, hm->bias_spec[f16 ? 1 : 0],
                        denoiser_strength, fbuf, Tmax, (float*)nullptr);
     hipLaunchKernelGGL(overlap_add_kernel, dim3(256, B), dim3(256), 0, s, fbuf, Tmax, d_frames, hop, wav2, (long long)Nld,
                        (long long)Nld);

@@ -287,15 +287,18 @@ struct HifiModel {
   std::vector<MrfStage> mrf;  // per stage
   int hop = 1;
   // denoiser bias spectrum |STFT(generator(zeros))|[:, 0] (larynx/hifi_gan.py:181-203), built on first use
+  // one per arithmetic: [0] the f32-plane modes, [1] the fp16 mode (the reference derives the bias from the model it runs,
+  // half or not: larynx/hifi_gan.py:181-203)
   std::mutex bias_mu;
-  float* bias_spec = nullptr;
-  bool bias_ready = false;
+  float* bias_spec[2] = {nullptr, nullptr};
+  bool bias_ready[2] = {false, false};
   ~HifiModel() {
     DeviceScope ds(device);
     if (arena) hipFree(arena);
     if (arena16) hipFree(arena16);
     if (arenaH) hipFree(arenaH);
-    if (bias_spec) hipFree(bias_spec);
+    for (float* b : bias_spec)
+      if (b) hipFree(b);
   }
 };
 

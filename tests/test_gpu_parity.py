@@ -735,6 +735,80 @@ def test_f16_config4_batch_rows(gpu_engine):
         gpu_engine.set_precision(v, ffi.PRECISION_F32)
 
 
+def test_f16_denoiser_uses_the_half_models_own_bias(gpu_engine):
+    """`denoiser_strength > 0` with the vocoder in fp16: the bias spectrum comes from the generator AS IT RUNS (the reference
+    derives it from the half model, larynx/hifi_gan.py:181-203) — cached per arithmetic, so switching modes never mixes them —
+    and the denoised waveform equals the oracle's STFT denoiser applied to the mode's own waveform with the mode's own bias."""
+    from larynx_amd import ffi
+    from oracle import denoise_np
+
+    c = load_case("ljspeech_medium_dave_ls12")
+    _, (vsd, v) = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    mb = gpu_engine.mel_from_numpy(c["mel_voc"])
+    strength = 0.1
+    f32_den, _ = gpu_engine.hifigan_infer(v, mb, denoiser_strength=strength)  # the f32 bias exists first
+    gpu_engine.set_precision(v, ffi.PRECISION_F16)
+    try:
+        plain, _ = gpu_engine.hifigan_infer(v, mb)
+        den, _ = gpu_engine.hifigan_infer(v, mb, denoiser_strength=strength)
+        bias = denoise_np.bias_spectrum(lambda m: gpu_engine.hifigan_infer(v, gpu_engine.mel_from_numpy(np.asarray(m, np.float32)[None]))[0][0])
+    finally:
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+    want = denoise_np.denoise(plain[0], bias, strength)
+    assert np.sqrt(np.mean((den[0] - want) ** 2)) <= 1e-5
+    assert np.sqrt(np.mean((den[0] - c["wav_denoised"]) ** 2)) <= 2 * float(c["ref_half_rms"])  # and near the reference's f32 result
+    again, _ = gpu_engine.hifigan_infer(v, mb, denoiser_strength=strength)
+    assert np.array_equal(again, f32_den)  # the f32 mode kept its own bias
+
+
+def test_f16_coalesced_calls(gpu_engine):
+    """Whole-call coalescing with the vocoder in fp16: eight threads' ragged batch-1 calls ride fused padded calls; frames identical
+    to the solitary calls.  A padded batch's acoustic pass differs from the solitary one at f32 round-off; in fp16 that is enough to
+    send roundings of the mel and of every later plane the other way, so the two waveforms are two draws of the mode's rounding
+    noise: each within the reference's own .half() deviation from the f32 truth (3.3e-4 RMS on 'high', tests/golden), their
+    difference within 1.5 x that (measured 2.7e-4)."""
+    import threading
+
+    from larynx_amd import ffi
+
+    (gsd, g), (vsd, v) = models(gpu_engine, HP.LJSPEECH, HP.HIFIGAN_HIGH)
+    s = ljspeech_audio_settings()
+    rng = np.random.default_rng(78)
+    lens = (120, 33, 64, 97, 120, 15, 81, 50)
+    ids = [synthetic.synthetic_phoneme_ids(rng, n, HP.LJSPEECH.num_symbols) for n in lens]
+
+    def call(i):
+        return gpu_engine.synthesize(g, v, ids[i], 0.667, 0.65, seed=900 + i, audio_settings=s, want_float=True, pad_before=11 * i,
+                                     frames_per_id_guess=20.0)
+
+    gpu_engine.set_precision(v, ffi.PRECISION_F16)
+    try:
+        gpu_engine.set_option("call_coalesce", 0)
+        solo = [call(i) for i in range(len(ids))]
+        gpu_engine.set_option("call_coalesce", 2)
+        p0, r0 = gpu_engine.coalesce_stats()
+        out = [None] * len(ids)
+        bar = threading.Barrier(len(ids))
+
+        def work(i):
+            bar.wait()
+            out[i] = call(i)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(ids))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        p1, r1 = gpu_engine.coalesce_stats()
+        assert r1 - r0 == len(ids) and p1 - p0 < r1 - r0
+        for (fa, wa, ia), (fb, wb, ib) in zip(solo, out):
+            assert np.array_equal(fa, fb) and ia.shape == ib.shape
+            assert np.sqrt(np.mean((wa - wb) ** 2)) <= 1.5 * 3.3e-4
+    finally:
+        gpu_engine.set_option("call_coalesce", gpu_engine.get_call_coalesce_default())
+        gpu_engine.set_precision(v, ffi.PRECISION_F32)
+
+
 def test_broadcast_weights_over_a_callers_rccl_communicator(gpu_engine):
     """`mi355tts_broadcast_weights`: the caller owns an RCCL communicator — here a one-rank
     one made with ctypes on the system's librccl —, the folded weight blob sits in device memory, the library
