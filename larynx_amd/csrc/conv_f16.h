@@ -89,6 +89,18 @@ __device__ __forceinline__ uint4 lrelu_h8(const uint4& v, _Float16 slope) {
 #ifndef F16_ABLATE
 #define F16_ABLATE 0  // probe builds only (tools/probe/f16_bench.hip): 1 = no epilogue, 2 = no MFMAs, 4 = no weight loads, 8 = no LDS reads, 16 = no staging
 #endif
+#ifndef F16_STAMPS  // probe builds only: thread 0 of every workgroup writes the cycle counter at phase boundaries to g_f16_stamps[wg][8]
+#define F16_STAMPS 0
+#endif
+#if F16_STAMPS
+__device__ unsigned long long* g_f16_stamps = nullptr;
+#define F16_STAMP(i)                                                                                                                \
+  do {                                                                                                                              \
+    if (threadIdx.x == 0 && g_f16_stamps) g_f16_stamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define F16_STAMP(i) ((void)0)
+#endif
 #ifndef F16_MIN_WAVES
 #define F16_MIN_WAVES 1  // __launch_bounds__' second argument: waves per SIMD the register allocation must leave room for
 #endif
@@ -260,6 +272,7 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
     lstore(1, 1, pre);
   }
   __syncthreads();
+  F16_STAMP(1);
 #pragma unroll
   for (int d = 0; d < BD; ++d) bread(0, d, Bf[d]);
 
@@ -268,6 +281,7 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf1 = buf == RING - 1 ? 0 : buf + 1, buf2 = RING < 3 ? 0 : (buf1 == 2 ? 0 : buf1 + 1);
     const bool more = RING == 3 && chunk + 2 < nchunks && !(F16_ABLATE & 16);
+    if (chunk == 2) F16_STAMP(5);
     if (more) gload(chunk + 2, pre);
     const int cb[3] = {chunk_base(chunk), chunk_base(chunk + 1), chunk_base(chunk + 2)};
     __builtin_amdgcn_sched_barrier(0);
@@ -307,9 +321,12 @@ __device__ __forceinline__ void conv_f16_mainloop(const HConvArgs& a, const int 
         for (int nb = 0; nb < NB; ++nb) Bf[d][nb] = Bf[d + 1][nb];
     }
     if (more) lstore(buf2, chunk + 2, pre);
+    if (chunk == 2) F16_STAMP(6);
     if (chunk + 1 < nchunks) __syncthreads();
+    if (chunk == 2) F16_STAMP(7);
     buf = buf1;
   }
+  F16_STAMP(2);
 }
 
 template <int K, int MB, int NB, int WM, int WN, int HALO, int CH, int EPI, bool MRF, int RING = 3>
@@ -328,6 +345,7 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
   const int Lout = a.out_len ? a.out_len[b] * a.out_mul : a.out_const;
   const int n_len = (EPI == EPI_UPSAMPLE) ? (Lin > 0 ? Lin + (K - 1) : 0) : Lout;
   if (t0 >= n_len) return;  // uniform per workgroup
+  F16_STAMP(0);
 
   // the residual is requested BEFORE the main loop (clamped addresses: nothing behind a branch) and consumed after it
   const int col = lane & 31;
@@ -409,6 +427,11 @@ __device__ __forceinline__ void conv_f16_tile(const HConvArgs& a, const int tile
       }
     }
   }
+  F16_STAMP(3);
+#if F16_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  F16_STAMP(4);
+#endif
 }
 
 template <int K, int EPI>

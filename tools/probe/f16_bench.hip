@@ -5,6 +5,7 @@
 // usage: f16_bench <Cin> <Cout> <K> <dil> <L> <cfg> [iters] [up]     (up > 0: polyphase upsampler with K = 2 taps)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -137,7 +138,7 @@ static int run_pair_group(int C, int dil, int L, int tile, int iters) {
   HPairGroupArgs g;
   std::memset(&g, 0, sizeof(g));
   g.n = 3;
-  const int tcols = tile == 0 ? 128 : 256;
+  const int tcols = tile == 0 ? 128 : tile == 5 ? 512 : 256;  // tile 4: 128 rows x 256 columns (waves of 64 x 128)
   int off = 0;
   double flop = 0;
   for (int m = 0; m < 3; ++m) {
@@ -172,6 +173,8 @@ static int run_pair_group(int C, int dil, int L, int tile, int iters) {
     constexpr int H0 = ConvHalo<11>::v, H1 = ConvHalo<7>::v, H2 = ConvHalo<3>::v;
     if (tile == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 2, 2, 2, H0, H1, H2, 32, 3, PROBE_PAIR_MINW>), grid, dim3(256), 0, nullptr, g);
     else if (tile == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 2, 1, 4, H0, H1, H2, 32, 2, PROBE_PAIR_MINW>), grid, dim3(256), 0, nullptr, g);
+    else if (tile == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 4, 2, 2, H0, H1, H2, 32, 3, 1>), grid, dim3(256), 0, nullptr, g);
+    else if (tile == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 2, 4, 1, 4, H0, H1, H2, 32, 2, 1>), grid, dim3(256), 0, nullptr, g);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pair_f16_group_kernel<11, 7, 3, 1, 2, 1, 4, H0, H1, H2, 32, 1, 4>), grid, dim3(256), 0, nullptr, g);
   };
   for (int i = 0; i < 3; ++i) go();
@@ -357,5 +360,37 @@ int main(int argc, char** argv) {
     std::printf("Cin %d Cout %d K %d dil %d L %d cfg %d up %d: %.2f us per launch, %.1f TFLOP/s (%.3f of 2500)\n", Cin, Cout, K, dil, L, cfg, up, us,
                 flop / us * 1e-6, flop / us * 1e-6 / 2500.0);
   }
+#if F16_STAMPS
+  {  // one more launch with the phase stamps read back: per workgroup start offset, prologue, main loop, epilogue, store tail
+    const size_t nwg = (size_t)grid.x * grid.y;
+    unsigned long long* ds;
+    HC(hipMalloc(&ds, nwg * 64));
+    HC(hipMemset(ds, 0, nwg * 64));
+    HC(hipMemcpyToSymbol(HIP_SYMBOL(g_f16_stamps), &ds, sizeof(ds)));
+    go(true);
+    HC(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(nwg * 8);
+    HC(hipMemcpy(st.data(), ds, nwg * 64, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, tend = 0;
+    for (size_t i = 0; i < nwg; ++i)
+      if (st[i * 8]) { t0 = std::min(t0, st[i * 8]); tend = std::max(tend, st[i * 8 + 4]); }
+    double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+    size_t n = 0;
+    for (size_t i = 0; i < nwg; ++i) {
+      if (!st[i * 8]) continue;
+      const double v[5] = {(double)(st[i * 8] - t0), (double)(st[i * 8 + 1] - st[i * 8]), (double)(st[i * 8 + 2] - st[i * 8 + 1]),
+                           (double)(st[i * 8 + 3] - st[i * 8 + 2]), (double)(st[i * 8 + 4] - st[i * 8 + 3])};
+      for (int k = 0; k < 5; ++k) { sum[k] += v[k]; mx[k] = std::max(mx[k], v[k]); }
+      ++n;
+    }
+    {
+      double c1 = 0, c2 = 0;
+      for (size_t i = 0; i < nwg; ++i) { c1 += (double)(st[i * 8 + 6] - st[i * 8 + 5]); c2 += (double)(st[i * 8 + 7] - st[i * 8 + 6]); }
+      std::printf("chunk 2: top -> before barrier avg %.0f, barrier avg %.0f\n", c1 / nwg, c2 / nwg);
+    }
+    std::printf("stamps (ticks; %zu workgroups; launch span %llu): start offset avg %.0f max %.0f | prologue avg %.0f max %.0f | main loop avg %.0f max %.0f | epilogue avg %.0f max %.0f | store tail avg %.0f max %.0f\n",
+                n, tend - t0, sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], sum[3] / n, mx[3], sum[4] / n, mx[4]);
+  }
+#endif
   return bad ? 1 : 0;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Soak test on one GPU: N host threads hammer one engine with random-length sentences on
-three resident voices and three vocoders ('high' exact, 'low' exact, 'high' in the split-bf16 mode), a share of
+three resident voices and five vocoders ('high' exact, 'low' exact, 'high' in the split-bf16 mode, 'high' and 'medium' in the
+native fp16 mode), a share of
 the calls through the fused one-call entry with pause padding, a share with the denoiser on; every
 result must be finite, of the expected length, identical when the whole job list is run a
 second time, and equal to a single-threaded recomputation for a sample.  VRAM use after
@@ -121,14 +122,17 @@ def main():
     s = ljspeech_audio_settings()
     from larynx_amd import ffi
 
-    vocs = [(hp, eng.load_hifigan(hp, synthetic.make_hifigan_state_dict(hp, seed=1234))) for hp in (HP.HIFIGAN_HIGH, HP.HIFIGAN_LOW, HP.HIFIGAN_HIGH)]
+    vocs = [(hp, eng.load_hifigan(hp, synthetic.make_hifigan_state_dict(hp, seed=1234)))
+            for hp in (HP.HIFIGAN_HIGH, HP.HIFIGAN_LOW, HP.HIFIGAN_HIGH, HP.HIFIGAN_HIGH, HP.HIFIGAN_MEDIUM)]
     eng.set_precision(vocs[2][1], ffi.PRECISION_BF16X3)
+    eng.set_precision(vocs[3][1], ffi.PRECISION_F16)
+    eng.set_precision(vocs[4][1], ffi.PRECISION_F16)
     voices = [(hp, eng.load_glow(hp, synthetic.make_glow_state_dict(hp, seed=1234))) for hp in (HP.LJSPEECH, HP.THORSTEN, HP.SIWIS)]
     rng = np.random.default_rng(99)
     jobs = []
     for i in range(args.calls):
         ghp, g = voices[int(rng.integers(3))]
-        vhp, v = vocs[int(rng.integers(3))]
+        vhp, v = vocs[int(rng.integers(len(vocs)))]
         B = 1 if rng.random() < 0.8 else int(rng.integers(2, 5))
         rows = [synthetic.synthetic_phoneme_ids(rng, int(rng.integers(1, 220)), ghp.num_symbols) for _ in range(B)]
         jobs.append((i, g, v, vhp, rows, 0.01 if rng.random() < 0.2 else 0.0, bool(rng.random() < 0.4)))
