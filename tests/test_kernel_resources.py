@@ -183,3 +183,26 @@ def test_two_workgroups_per_cu_where_the_schedule_counts_on_it(resources):
             assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["lds"] <= 80 * 1024, ((K, ci, MB, NB, WN, KS, WM), r)
     # every workgroup of 512 threads needs at least 2 waves per SIMD
     assert all(r["occupancy"] >= 2 for r in conv.values())
+
+
+def test_fp16_mode_kernels(resources):
+    """The native fp16 vocoder (conv_f16.h / pair_f16.h): no kernel of the mode touches scratch; the fused 128- and 64-channel
+    steps fit three waves per SIMD (168 VGPRs) and three workgroups per CU of LDS, the fused narrow steps four waves and 21 KB;
+    the un-fused tiles stay at two waves per SIMD (what the 256-channel stage and the upsamplers were measured on)."""
+    f16 = {n: r for n, r in resources.items() if "conv_f16" in n or "pair_f16" in n or "post_f16" in n or "pack_octets" in n}
+    assert len(f16) >= 25, sorted(f16)
+    for n, r in f16.items():
+        assert r["scratch"] == 0, (n, r)
+    pairs = {n: r for n, r in f16.items() if "pair_f16_group_kernel" in n}
+    assert len(pairs) == 3
+    for n, r in pairs.items():
+        # pair_f16_group_kernel<K0, K1, K2, MB, NB, WM, WN, ...>: WM = 2 -> the 128-row tile, MB = 1 -> the 32-row tile
+        wide = "ILi11ELi7ELi3ELi2ELi2ELi2ELi2E" in n
+        slim = "ILi11ELi7ELi3ELi1ELi2ELi1ELi4E" in n
+        if slim:
+            assert r["occupancy"] >= 4 and r["lds"] <= 21 * 1024, (n, r)
+        else:
+            assert r["occupancy"] == 3 and r["vgprs"] <= 168 and r["lds"] <= (40 if wide else 42) * 1024, (n, r)
+    for n, r in f16.items():
+        if "conv_f16" in n:
+            assert r["occupancy"] >= 2 and r["lds"] <= 42 * 1024, (n, r)
