@@ -457,6 +457,9 @@ def main():
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
     ap.add_argument("--tiny-half", action="store_true", help="with --tiny: run the half-mode (fp16) and split-bf16 legs too (they are skipped on the emulator by default)")
+    ap.add_argument("--half-acoustic", default="f16", choices=["f16", "f32"],
+                    help="the acoustic model in the fp16 mode (half_mode leg, --precision f16): f16 = the decoder's WaveNets in fp16 "
+                         "(csrc/wn_f16.h), f32 = only the vocoder takes the switch")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "bf16x3"],
                     help="f32 = exact f32 MFMA everywhere (the graded parity mode); f16 = the `half` switch: the native fp16 vocoder "
                          "(fp16 planes, one fp16 MFMA per product); bf16x3 = split-bf16 ResBlock convs (3 x bf16 MFMA per product, f32 planes)")
@@ -567,6 +570,8 @@ def main():
         eng.set_precision(v, ffi.PRECISION_BF16X3)
     elif args.precision == "f16":
         eng.set_precision(v, ffi.PRECISION_F16)
+        if args.half_acoustic == "f16":
+            eng.set_precision(g, ffi.PRECISION_F16)
 
     # ---- synthetic utterances (one per step per rank), resident in HBM
     rng = np.random.default_rng(1234 + rank)
@@ -809,8 +814,11 @@ def main():
     # exact f32 mode).  Same steps, same method, fewer repeats.  Next to it the split-bf16 mode (f32-class accuracy), in-flight only.
     half = None
     x3_flight = 0.0
+    glow_f16 = False
     if args.precision == "f32" and (not args.tiny or args.tiny_half) and not args.no_half_mode:
         eng.set_precision(v, ffi.PRECISION_F16)
+        # `half` on the acoustic model: the decoder's WaveNets in fp16 (0), or a reported no-op on a geometry wn_f16.h does not cover
+        glow_f16 = args.half_acoustic == "f16" and eng.set_precision(g, ffi.PRECISION_F16) == 0
         run_steps(0, max(W, conc))
         step(W)
         eng.set_profiling(True)
@@ -824,6 +832,7 @@ def main():
         eng.set_profiling(False)
         h_single = timed(lambda: run_steps(W, n_utts, threads=1), max(3, repeats // 3))
         h_flight = timed(lambda: run_steps(W, n_utts), max(3, repeats // 3)) if conc > 1 else h_single
+        eng.set_precision(g, ffi.PRECISION_F32)
         eng.set_precision(v, ffi.PRECISION_BF16X3)
         run_steps(0, max(W, conc))
         x3_flight = med(timed(lambda: run_steps(W, n_utts), max(3, repeats // 3)))
@@ -1094,11 +1103,16 @@ def main():
             "half_mode": None if not half else {
                 "dtype": "f16: the native fp16 vocoder — fp16 weights, fp16 activation planes in HBM between ALL layers (conv_pre, upsamplers, every "
                          "ResBlock conv, conv_post), one v_mfma_f32_32x32x16_f16 per product, f32 accumulate (csrc/conv_f16.h, hifigan_f16.h); "
-                         "GlowTTS stays f32 (mi355tts_model_set_precision reports the switch as a no-op there)",
-                "what": "the reference's `half` switch (`.half()` on the generator, larynx/hifi_gan.py:96-97) on this backend; NOT the headline — reported next to it",
-                "parity": "waveform error vs the reference's f32 output no larger than the reference's OWN generator under .half() on the same "
-                          "input (tests/golden/*.npz: ref_half_rms, made by oracle/make_golden.py); asserted per golden case in "
-                          "tests/test_gpu_parity.py::test_f16_mode_against_the_reference and ::test_f16_fused_call_against_the_reference",
+                         + ("GlowTTS: the decoder's WaveNets in fp16, one launch per coupling block (csrc/wn_f16.h); encoder, durations, "
+                            "start / end convs, coupling and InvConvNear in f32" if glow_f16 else "GlowTTS in f32"),
+                "acoustic_model": "f16 decoder WaveNets (wn_f16_kernel)" if glow_f16 else "f32",
+                "what": "the reference's `half` switch (`.half()` on both models, larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97) on this backend; "
+                        "NOT the headline — reported next to it",
+                "parity": "vocoder: waveform error vs the reference's f32 output no larger than the reference's OWN generator under .half() on the same "
+                          "input (tests/golden/*.npz: ref_half_rms, made by oracle/make_golden.py); acoustic model: mel error no larger than the "
+                          "reference's OWN decoder under .half() (tests/golden/glow_half_reference.json, oracle/make_golden_glow_half.py); both: the fused "
+                          "call within the reference's two models under .half().  Asserted per golden case in tests/test_gpu_parity.py::"
+                          "test_f16_mode_against_the_reference, ::test_f16_acoustic_mode_against_the_reference, ::test_f16_fused_call_against_the_reference",
                 "utterances_per_sec": world * K * B / dt_half_flight,
                 "ms_per_step": 1e3 * dt_half_flight / K,
                 "latency_ms_single_stream": 1e3 * dt_half_single / K,

@@ -128,9 +128,16 @@ int mi355tts_broadcast_weights(mi355tts_ctx* ctx, void* nccl_comm, int root, flo
  * MI355TTS_PRECISION_BF16X3: the accurate reduced mode — the HiFi-GAN ResBlock convs and upsamplers run on the bf16 matrix cores
  * with split operands (x = hi + lo, three bf16 MFMAs per product, f32 accumulate, f32 planes): ~1e-5 relative error per layer.
  * MI355TTS_PRECISION_BF16: the BF16X3 kernels with ONE bf16 MFMA per product (kept for A/B runs).
- * GlowTTS models always compute in exact f32 (4 % of the path's FLOPs, launch-bound: no speed to buy): a request for any other
- * precision on a GlowTTS model changes nothing and returns MI355TTS_PRECISION_NOOP (= 1, a positive status: not an error, not a
- * silent success); MI355TTS_PRECISION_F32 returns 0. */
+ * GlowTTS models (the reference calls `.half()` on the whole FlowGenerator, larynx/glow_tts.py:90-91): MI355TTS_PRECISION_F16
+ * puts the decoder's WaveNets — every gate conv and res_skip of every coupling block (glow_tts/layers.py:138-162): 84 % of the
+ * acoustic model's FLOPs and 97 of its ~140 launches — on the fp16 matrix cores, ONE launch per block (csrc/wn_f16.h: fp16 weights,
+ * hidden state and gated activations, f32 accumulation, f32 skip sum).  The encoder, the duration predictor (so the FRAME COUNTS
+ * are the f32 model's: the reference's whole-model .half() changes them on 3 of 8 golden cases), the start / end convs, the
+ * affine coupling, InvConvNear and ActNorm stay f32.  Accuracy: the mel within the error of the reference's own decoder under
+ * .half() (tests/golden/glow_half_reference.json, made by oracle/make_golden_glow_half.py).  The kernel covers hidden_channels
+ * 192 (the released voices; 32 for tests), kernel_size_dec 5, dilation_rate 1, single-speaker models; on any other GlowTTS
+ * geometry, and for the split-bf16 requests on every GlowTTS model, the request changes nothing and returns
+ * MI355TTS_PRECISION_NOOP (= 1, a positive status: not an error, not a silent success).  MI355TTS_PRECISION_F32 returns 0. */
 #define MI355TTS_PRECISION_F32 0
 #define MI355TTS_PRECISION_BF16X3 1
 #define MI355TTS_PRECISION_BF16 2

@@ -65,6 +65,36 @@ static int run_glow_tail(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, cons
   return 0;
 }
 
+// the fp16 mode's WaveNet of block `Bk` (wn_f16.h): every layer's gate conv and res_skip but the last res_skip in ONE launch;
+// leaves `acts` (last layer's gated activations) and `skip` (layers 0 .. n - 2) as the f32 chain would.  1 = not taken.
+static int run_wn_f16(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const GlowBlock& Bk, const float* hcur, float* acts, float* skip,
+                      long long bsD, int F2, const int* d_f2, int host_len, int B, int F2max) {
+  const mi355tts_glow_hparams& h = gm->hp;
+  const int H = h.hidden_channels, n = h.n_block_layers;
+  if (!gm->f16_ok || (int)Bk.h_in.size() != n || (int)Bk.h_rs.size() != n - 1 || F2max <= 0 || (H != 192 && H != 32)) return 1;
+  WnF16Args a;
+  std::memset(&a, 0, sizeof(a));
+  a.h = hcur; a.bs = bsD; a.ld = F2;
+  if (B == 1 && host_len >= 0) { a.len = nullptr; a.len_const = host_len; } else { a.len = d_f2; }
+  for (int j = 0; j < n; ++j) {
+    a.w_in[j] = Bk.h_in[j].w; a.b_in[j] = Bk.h_in[j].bias;
+    if (j < n - 1) { a.w_rs[j] = Bk.h_rs[j].w; a.b_rs[j] = Bk.h_rs[j].bias; }
+  }
+  a.n_layers = n;
+  a.margin = (h.kernel_size_dec - 1) / 2 * n;
+  a.acts = acts; a.skip = skip;
+  const int to = WN_W - 2 * a.margin;
+  const dim3 grid((F2max + to - 1) / to, B);
+  const double mac = (double)n * 2.0 * H * H * h.kernel_size_dec + (double)(n - 1) * 2.0 * H * H;
+  ProfScope ps(ctx, w, KC_GLOW_DEC_CONV, 2.0 * mac * (double)F2max * B);
+  if (H == 192)
+    hipLaunchKernelGGL((wn_f16_kernel<5, 24, 3>), grid, dim3(256), 0, w->stream, a);
+  else
+    hipLaunchKernelGGL((wn_f16_kernel<5, 4, 1>), grid, dim3(256), 0, w->stream, a);
+  kn_hit(ctx, KN_WN_F16);
+  return 0;
+}
+
 // LayerNorm -> [ReLU] -> conv with the norm inside the conv launch (lin16_kernel's LN prologue) when the shape has one;
 // otherwise the LayerNorm launch (raw -> normed) and the conv on its output.  `normed` may be nullptr when nothing else
 // reads the normalised tensor AND the fused form is taken; the fallback needs a buffer: `scratch`.
@@ -229,6 +259,8 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
   w->o_glow_fuse = ctx->glow_fuse.load();  // one read per call: the launch helpers below use the snapshot
   w->o_gate16 = ctx->gate16.load();
   w->o_gate16_wide = ctx->gate16_wide.load();
+  // the `half` switch as this call saw it at its start: the decoder's WaveNets in fp16 (wn_f16.h)
+  const bool glow_f16 = gm->f16_ok && gm->precision.load() == MI355TTS_PRECISION_F16;
   const float* A = gm->arena;
   const int H = h.hidden_channels, Fc = h.filter_channels, Fd = h.filter_channels_dp, M = h.mel_channels;
   const int k = h.kernel_size, nh = h.n_heads;
@@ -540,7 +572,9 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
     }
     int dil = 1;
     bool tail_done = false;
-    for (int j = 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
+    // the fp16 mode: layers 0 .. n - 1 up to the last gated tile in ONE launch (wn_f16.h); the loop then runs the last layer's tail
+    const bool wn16 = glow_f16 && run_wn_f16(ctx, w, gm, Bk, hcur, acts, skip, bsD, F2, d_f2, dec_host_len, B, F2max) == 0;
+    for (int j = wn16 ? h.n_block_layers - 1 : 0; j < h.n_block_layers; ++j) {  // WN.forward, layers.py:138-162
       const int kd = h.kernel_size_dec;
       const bool last = j == h.n_block_layers - 1;
       ConvArgs a = base_args(hcur, bsD, F2, d_f2, 1, acts, bsD, F2, d_f2, 1, dil, (kd * dil - dil) / 2);
@@ -553,7 +587,7 @@ static int glow_run(mi355tts_ctx* ctx, Worker* w, const GlowModel* gm, const Glo
         a.in_len = a.out_len = nullptr;
         a.in_const = a.out_const = dec_host_len;
       }
-      {
+      if (!wn16) {
         const int g16 = run_gate16(ctx, w, Bk.in[j], a, B, F2max, KC_GLOW_DEC_CONV, s);
         if (g16 < 0) return g16;
         if (g16 == 1) CHECK(launch_conv(ctx, w, Bk.in[j], a, EPI_GATE, B, F2max, KC_GLOW_DEC_CONV, nullptr, glow_tiles, dec_host_len));

@@ -73,6 +73,32 @@ static HConvW add_ups_h(HPackSink& sk, const float* wt, const float* bias, int C
                     [&](int v) { return bias[v % Cout]; }, bias != nullptr),
                 Cin);
 }
+// ---- the WaveNets of GlowTTS' coupling blocks for wn_f16_kernel (wn_f16.h)
+static std::string glow_f16_unsupported(const mi355tts_glow_hparams& h) {
+  if (h.hidden_channels != 192 && h.hidden_channels != 32) return "hidden_channels other than 192 (32)";
+  if (h.kernel_size_dec != 5) return "kernel_size_dec other than 5";
+  if (h.dilation_rate != 1) return "dilated WaveNet layers";
+  if (h.n_speakers > 1) return "speaker conditioning";
+  if (h.n_block_layers < 1 || h.n_block_layers > WN_MAX_LAYERS || 4 * h.n_block_layers >= WN_W) return "n_block_layers";
+  return "";
+}
+// in_layers[j]: w [2H][H][K]; virtual 32-row tile p = the tanh rows of channels 16 p .. 16 p + 15, then their sigmoid rows
+static HConvW add_wn_gate_h(HPackSink& sk, const float* w, const float* bias, int H, int K) {
+  auto row_of = [H](int v) {
+    const int p = v / 32, i = v % 32, c = 16 * p + (i & 15);
+    return i < 16 ? c : H + c;
+  };
+  return sk.add(pack_conv_f16(
+                    2 * H, 1, H, K, 32, [&](int v, int ci, int k) { return w[((size_t)row_of(v) * H + ci) * K + k]; },
+                    [&](int v) { return bias[row_of(v)]; }, true),
+                H);
+}
+// res_skip_layers[j] (j < n - 1): w [2H][H][1], rows in natural order [res | skip]
+static HConvW add_wn_rs_h(HPackSink& sk, const float* w, const float* bias, int H) {
+  return sk.add(pack_conv_f16(
+                    2 * H, 1, H, 1, 32, [&](int v, int ci, int) { return w[(size_t)v * H + ci]; }, [&](int v) { return bias[v]; }, true),
+                H);
+}
 static void fix_h(HConvW& c, const uint16_t* arenaH, const float* arena) {
   c.w = reinterpret_cast<const uint4*>(arenaH + c.w_off);
   c.bias = arena + c.b_off;

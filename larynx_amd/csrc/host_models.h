@@ -185,6 +185,16 @@ struct Blob {
   }
 };
 
+// one conv of the fp16 modes (conv_f16.h, wn_f16.h): fp16 A fragments in the model's fp16 arena, f32 bias in the float arena
+struct HConvW {
+  size_t w_off = 0, b_off = 0;  // uint16 elements into arenaH; floats into the model arena
+  const uint4* w = nullptr;
+  const float* bias = nullptr;
+  int mtiles = 0, nslab = 0, K = 0, rows = 0, Cin = 0;
+};
+struct HResConv {
+  HConvW c1, c2;
+};
 struct GlowLayer {
   DevConv qkv, o, ffn1, ffn2;
   size_t ek, ev, g1, b1, g2, b2;
@@ -196,6 +206,8 @@ struct GlowBlock {
   size_t winv, an_bias, an_scale;
   // the column-owner packings of glow_tail_kernel (coltile.h): res_skip_layers[last], end (rows in natural order), start
   DevCol t_rs, t_end, t_st;
+  // fp16 packings of the WaveNet for wn_f16_kernel: in_layers (rows paired per 32-row tile), res_skip_layers[0 .. n - 2]
+  std::vector<HConvW> h_in, h_rs;
 };
 // Models are handed out as shared_ptr pins: a call keeps its models alive for its whole duration, mi355tts_unload only
 // drops the context's reference, and the device memory goes when the last call that uses the model has returned.
@@ -217,12 +229,16 @@ struct GlowModel {
   mi355tts_glow_hparams hp;
   int device = 0;
   float* arena = nullptr;
-  std::atomic<int> precision{0};  // the `half` switch (see HifiModel::precision)
+  // the `half` switch: MI355TTS_PRECISION_F16 = the decoder's WaveNets in fp16 (wn_f16.h) when the geometry is covered
+  // (f16_ok; f16_why says what is not); everything else of the acoustic model computes in f32 in every mode
+  std::atomic<int> precision{0};
+  uint16_t* arenaH = nullptr;
+  bool f16_ok = false;
+  std::string f16_why;
   ~GlowModel() {
-    if (arena) {
-      DeviceScope ds(device);
-      hipFree(arena);
-    }
+    DeviceScope ds(device);
+    if (arena) hipFree(arena);
+    if (arenaH) hipFree(arenaH);
   }
   size_t emb;
   std::vector<DevConv> pre_conv;
@@ -251,16 +267,6 @@ struct MrfStage {
   int woff[3][MRF_MAX_STEPS][2] = {};
   int dil[3][MRF_MAX_STEPS] = {};
   double mac_per_col = 0;  // algorithmic MACs per output column (all 18 convs)
-};
-// one conv of the native fp16 vocoder (conv_f16.h): fp16 A fragments in the model's fp16 arena, f32 bias in the float arena
-struct HConvW {
-  size_t w_off = 0, b_off = 0;  // uint16 elements into arenaH; floats into the model arena
-  const uint4* w = nullptr;
-  const float* bias = nullptr;
-  int mtiles = 0, nslab = 0, K = 0, rows = 0, Cin = 0;
-};
-struct HResConv {
-  HConvW c1, c2;
 };
 struct HifiModel {
   mi355tts_hifigan_hparams hp;

@@ -41,6 +41,7 @@
 #include "small_kernels.h"
 #include "conv_f16.h"
 #include "pair_f16.h"
+#include "wn_f16.h"
 #include "weights_pack.h"
 
 using namespace mi355tts;
@@ -326,6 +327,11 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
   }
   const int C = M * h.n_sqz, half = C / 2;
   std::vector<float> cond_w_all, cond_b_all;
+  // the fp16 form of the decoder's WaveNets (wn_f16.h), when the geometry is one its kernel is built for
+  gm->f16_why = glow_f16_unsupported(h);
+  gm->f16_ok = gm->f16_why.empty();
+  HPackSink gsink;
+  gsink.ab = &ab;
   for (int b = 0; b < h.n_blocks_dec; ++b) {
     GlowBlock B;
     std::string an = "decoder.flows." + std::to_string(3 * b);
@@ -363,6 +369,10 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
       B.rs.push_back(add_conv(ab, wr, br, rsn, H, 1, ROWS_PLAIN));
       add_lin16(ab, B.rs.back(), wr, br, rsn, H, 1);
       if (j == h.n_block_layers - 1) B.t_rs = add_col16(ab, wr, br, H, H);
+      if (gm->f16_ok) {
+        B.h_in.push_back(add_wn_gate_h(gsink, wi, bi, H, h.kernel_size_dec));
+        if (j < h.n_block_layers - 1) B.h_rs.push_back(add_wn_rs_h(gsink, wr, br, H));
+      }
     }
     TAKE(we, cp + ".end.weight", (int64_t)C * H);
     TAKE(be, cp + ".end.bias", C);
@@ -394,6 +404,15 @@ extern "C" int mi355tts_load_glow(mi355tts_ctx* ctx, const mi355tts_glow_hparams
     fix(B.end, A);
     for (auto& c : B.in) fix(c, A);
     for (auto& c : B.rs) fix(c, A);
+  }
+  if (gm->f16_ok) {
+    hipError_t e = hipMalloc(&gm->arenaH, gsink.w.size() * sizeof(uint16_t) + 256);
+    if (e != hipSuccess) return fail(MI355TTS_ERR_NOMEM, "hipMalloc fp16 weight arena: %s", hipGetErrorString(e));
+    HIPCHECK(hipMemcpy(gm->arenaH, gsink.w.data(), gsink.w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    for (auto& B : gm->blocks) {
+      for (auto& c : B.h_in) fix_h(c, gm->arenaH, A);
+      for (auto& c : B.h_rs) fix_h(c, gm->arenaH, A);
+    }
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
   const int id = ctx->next_id++;
@@ -701,9 +720,17 @@ extern "C" int mi355tts_model_set_precision(mi355tts_ctx* ctx, int model, int pr
     v->second->precision.store(precision);
     return 0;
   }
-  // GlowTTS (4 % of the path's FLOPs) always computes in exact f32: a reduced-precision request is REPORTED as having no
-  // effect (a distinct positive status, not an error and not a silent success); F32 is what it runs anyway
-  if (ctx->glow.find(model) != ctx->glow.end()) return precision == MI355TTS_PRECISION_F32 ? 0 : MI355TTS_PRECISION_NOOP;
+  // GlowTTS: MI355TTS_PRECISION_F16 puts the decoder's WaveNets — 84 % of the acoustic model's FLOPs, 97 of its ~140 launches —
+  // on the fp16 matrix cores (wn_f16.h) where the geometry is covered; the split-bf16 requests, and F16 on a geometry the
+  // kernel is not built for, are REPORTED as having no effect (a distinct positive status: not an error, not a silent success)
+  auto gi = ctx->glow.find(model);
+  if (gi != ctx->glow.end()) {
+    if (precision == MI355TTS_PRECISION_F32 || (precision == MI355TTS_PRECISION_F16 && gi->second->f16_ok)) {
+      gi->second->precision.store(precision);
+      return 0;
+    }
+    return MI355TTS_PRECISION_NOOP;
+  }
   return fail(MI355TTS_ERR_NO_MODEL, "no model %d", model);
 }
 

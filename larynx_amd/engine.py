@@ -134,10 +134,10 @@ class Engine:
                                                                 int(numel), lib_name))
 
     def set_precision(self, model: int, precision: int):
-        """`ffi.PRECISION_F32` (exact, default), `ffi.PRECISION_F16` (native fp16 vocoder: the reference's `half` switch)
-        or `ffi.PRECISION_BF16X3` (split-bf16, f32-class accuracy).  Returns the library's status: 0, or
-        `ffi.PRECISION_NOOP` when the model (GlowTTS) computes in f32 regardless.  Raises when fp16 does not cover the
-        vocoder's geometry."""
+        """`ffi.PRECISION_F32` (exact, default), `ffi.PRECISION_F16` (the reference's `half` switch: native fp16 vocoder; on a
+        GlowTTS model the decoder's WaveNets in fp16) or `ffi.PRECISION_BF16X3` (split-bf16, f32-class accuracy; vocoder only).
+        Returns the library's status: 0, or `ffi.PRECISION_NOOP` when the request has no effect on this GlowTTS model (it keeps
+        computing in f32).  Raises when fp16 does not cover the vocoder's geometry."""
         return ffi.check(self.lib, self.lib.mi355tts_model_set_precision(self._ctx, int(model), int(precision)))
 
     def unload(self, model: int):

@@ -26,8 +26,8 @@ ABI_VERSION = 2  # MI355TTS_ABI_VERSION of include/mi355tts.h
 PRECISION_F32 = 0
 PRECISION_BF16X3 = 1
 PRECISION_BF16 = 2
-PRECISION_F16 = 3  # native fp16 vocoder (csrc/conv_f16.h): the reference's `.half()`
-PRECISION_NOOP = 1  # mi355tts_model_set_precision's return on a GlowTTS model: accepted, no effect
+PRECISION_F16 = 3  # the reference's `.half()`: native fp16 vocoder (csrc/conv_f16.h), fp16 decoder WaveNets of GlowTTS (csrc/wn_f16.h)
+PRECISION_NOOP = 1  # mi355tts_model_set_precision's return on a GlowTTS model the fp16 kernel does not cover: accepted, no effect
 
 
 class GlowHParamsC(C.Structure):

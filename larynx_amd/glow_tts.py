@@ -44,8 +44,8 @@ class HipGlowTextToSpeech(TextToSpeechModel):
         super().__init__(config)
         if config.backend not in (None, InferenceBackend.HIP):
             raise ValueError(f"Unknown backend: {config.backend}")
-        # `half` (larynx/glow_tts.py:90-91) is accepted: GlowTTS is 4 % of the path's FLOPs and keeps computing in
-        # exact f32; the switch acts on the vocoder (HipHiFiGanVocoder), where 93 % of the FLOPs are
+        # `half` (larynx/glow_tts.py:90-91 calls `.half()` on the model): the decoder's WaveNets run in fp16 (csrc/wn_f16.h) where
+        # the library's kernel covers the geometry (the released voices'); the encoder and the durations stay f32
         self.engine = get_engine(device, library_path)
         cfg = model_config if model_config is not None else read_config(config.model_path)
         self.hparams = GlowHParams.from_config(cfg)
@@ -56,7 +56,7 @@ class HipGlowTextToSpeech(TextToSpeechModel):
             state_dict = load_state_dict(ckpt, "model", manifest_names=names, n_split=self.hparams.n_split)
         self.model_id = self.engine.load_glow(self.hparams, state_dict)
         if config.half and self.engine.set_precision(self.model_id, ffi.PRECISION_F16) == ffi.PRECISION_NOOP:
-            _LOGGER.debug("half: the acoustic model computes in f32 (the library reports the switch as a no-op for GlowTTS)")
+            _LOGGER.debug("half: the acoustic model computes in f32 (the library reports the switch as a no-op for this geometry)")
         self.noise_scale = 0.667
         self.length_scale = 1.0
         self._audio_settings: typing.Optional[AudioSettings] = None

@@ -66,7 +66,7 @@ def import_reference():
     return gm, hm, hc, ra
 
 
-def build_ref_glow(gm, hp: HP.GlowHParams, sd):
+def build_ref_glow(gm, hp: HP.GlowHParams, sd, prepare=None):
     import torch
 
     model = gm.FlowGenerator(
@@ -98,6 +98,8 @@ def build_ref_glow(gm, hp: HP.GlowHParams, sd):
     )
     tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
     missing, unexpected = model.load_state_dict(tsd, strict=True), None
+    if prepare is not None:  # e.g. `.half()`, which larynx/glow_tts.py:90-94 applies BEFORE store_inverse()
+        prepare(model)
     model.decoder.store_inverse()  # larynx/glow_tts.py:94
     model.eval()
     return model

@@ -34,3 +34,9 @@ def load_batch8():
         wav=[z[f"wav{b}"] for b in range(8)],
         ref_half_rms=[float(z[f"ref_half_rms{b}"]) for b in range(8)],  # the reference's generator under .half() vs its own f32 waveform
     )
+
+
+def load_glow_half_reference():
+    """Per golden case: what the reference's own decoder under .half() (and both models under .half()) costs against its f32
+    outputs (oracle/make_golden_glow_half.py) — the bar of the HIP library's fp16 acoustic mode."""
+    return json.loads((GOLDEN / "glow_half_reference.json").read_text())

@@ -193,10 +193,10 @@ def test_unsupported_requests_raise(emu_library, voice_dirs):
 
 def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
     """`half=True` (the reference's registry default for voices, larynx/__init__.py:297; `.half()` at
-    larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97): GlowTTS keeps computing in f32 (the library reports the switch as a
-    no-op there), the vocoder runs its native fp16 mode (csrc/conv_f16.h) — same interface, audio within a half-precision
-    band of the exact mode (the reference's own generator under .half() moves the int16 samples by 40 - 85 LSB on the golden
-    set: tests/golden/*.npz, ref_half_i16)."""
+    larynx/glow_tts.py:90-91, larynx/hifi_gan.py:96-97): the acoustic model's decoder WaveNets run in fp16 (csrc/wn_f16.h), the
+    vocoder runs its native fp16 mode (csrc/conv_f16.h) — same interface, audio within a half-precision band of the exact mode
+    (the reference's own models under .half() move the int16 samples by 340 - 470 LSB on the golden set:
+    tests/golden/glow_half_reference.json, both_half_i16; its generator alone by 40 - 85: tests/golden/*.npz, ref_half_i16)."""
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=128,
                            resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3), (1, 3), (1, 5)), num_mels=16)
     gdir, vdir = tmp_path / "half-glow_tts", tmp_path / "half_hifi_gan"
@@ -216,7 +216,7 @@ def test_half_switch_is_accepted_like_the_reference(emu_library, tmp_path):
         out[half] = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
     assert out[True].shape == out[False].shape and out[True].dtype == np.int16
     d = np.abs(out[True].astype(np.int32) - out[False].astype(np.int32))
-    assert d.max() <= 128 and not np.array_equal(out[True], out[False])
+    assert d.max() <= 512 and not np.array_equal(out[True], out[False])
 
 
 @pytest.mark.gpu
@@ -226,8 +226,9 @@ def test_full_size_voice_through_sentence_task_on_the_device(tmp_path, half):
     hifi_gan 'high' checkpoints (seeded synthetic weights — the goldens' own), `HipGlowTextToSpeech` / `HipHiFiGanVocoder` built
     by the registry functions, `larynx_amd.sentence_task` as `/root/reference/larynx/__init__.py:229-257` runs it, against the
     reference-made golden of the bench utterance (`ljspeech_high_S120`): int16 within 1 LSB in the exact mode; with `half=True`
-    (the registry's default for voices, larynx/__init__.py:297) within the reference's OWN .half() deviation on that case."""
-    from tests.golden_util import load_case
+    (the registry's default for voices, larynx/__init__.py:297: BOTH models take it) within the deviation of the reference's OWN
+    models under .half() on that case (tests/golden/glow_half_reference.json: both_half_i16)."""
+    from tests.golden_util import load_case, load_glow_half_reference
 
     c = load_case("ljspeech_high_S120")
     gdir, vdir = tmp_path / "ljspeech-glow_tts", tmp_path / "hifi_gan_universal_large"
@@ -250,6 +251,6 @@ def test_full_size_voice_through_sentence_task_on_the_device(tmp_path, half):
     audio = larynx_amd.sentence_task("golden", [int(i) for i in c["ids"]], getattr(tts, "audio_settings"), tts, settings, voc, None)
     assert audio.dtype == np.int16 and audio.shape == c["wav_i16"].shape
     d = int(np.abs(audio.astype(np.int32) - c["wav_i16"].astype(np.int32)).max())
-    assert d <= (1.5 * int(c["ref_half_i16"]) if half else 1), d
+    assert d <= (int(load_glow_half_reference()["ljspeech_high_S120"]["both_half_i16"]) if half else 1), d
     if half:
-        assert d > 1  # the fp16 mode really ran
+        assert d > 1  # the fp16 modes really ran

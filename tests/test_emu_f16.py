@@ -141,10 +141,11 @@ def test_f16_is_refused_with_a_reason_where_it_does_not_apply(emu_engine):
         emu_engine.set_precision(v, ffi.PRECISION_BF16X3)  # the accurate reduced mode still applies
     finally:
         emu_engine.unload(v)
-    # GlowTTS: accepted, reported as a no-op
+    # GlowTTS: fp16 = the decoder's WaveNets (csrc/wn_f16.h; tests/test_emu_glow_f16.py); the split-bf16 requests are accepted and
+    # reported as a no-op
     g = emu_engine.load_glow(HP.TINY_GLOW, synthetic.make_glow_state_dict(HP.TINY_GLOW, seed=1))
     try:
-        assert emu_engine.set_precision(g, ffi.PRECISION_F16) == ffi.PRECISION_NOOP
+        assert emu_engine.set_precision(g, ffi.PRECISION_F16) == 0
         assert emu_engine.set_precision(g, ffi.PRECISION_BF16X3) == ffi.PRECISION_NOOP
         assert emu_engine.set_precision(g, ffi.PRECISION_F32) == 0
     finally:
