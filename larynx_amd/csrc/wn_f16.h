@@ -37,8 +37,41 @@ struct WnF16Args {
   float* skip;  // [B][H][ld]: sum over layers 0 .. n - 2 of their skip halves (biases included); unused when n_layers == 1
 };
 
-// NOCT = H / 8 octet rows of the hidden state; MTW = 32-row tiles a wave carries (2H / 32 tiles over 4 waves)
-template <int KD, int NOCT, int MTW>
+// tanh(ta) * sigmoid(sb) (glow_tts/utils.py:31-38) from two v_exp_f32 and one v_rcp_f32: (1 - e^-2ta) / ((1 + e^-2ta) (1 + e^-sb)).
+// ta is clamped to +-15 (tanh is 1 to 13 digits there; e^30 stays finite); a huge e^-sb gives rcp(inf) = 0 = sigmoid's limit.
+__device__ __forceinline__ float gate_fast(float ta, float sb) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  ta = fminf(fmaxf(ta, -15.0f), 15.0f);
+  const float ea = __builtin_amdgcn_exp2f(-2.0f * LOG2E * ta);
+  const float eb = __builtin_amdgcn_exp2f(-LOG2E * sb);
+  return (1.0f - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
+}
+
+// issue order of a step (conv_f16.h's): the MTW weight loads behind the first MFMAs, then the two LDS reads, then the barrier that keeps
+// the scheduler from sinking the next steps' loads to their first use (0x008 = MFMA, 0x020 = VMEM read, 0x100 = LDS read)
+#define WN_STEP_ORDER()                                                          \
+  do {                                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2 * MTW; ++q_) {                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+      if (q_ < MTW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           \
+      else if (q_ - MTW < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+    }                                                                            \
+    if (MTW < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 - MTW, 0);        \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+
+// NOCT = H / 8 octet rows of the hidden state; MTW = 32-row tiles a wave carries (2H / 32 tiles over 4 waves); AD = weight
+// fragments in flight ahead of the MFMAs that use them, in steps.
+//
+// The weight stream.  A wave's A fragments come straight from L2 (every workgroup of the launch reads the same 3 MB of a block's
+// weights; a wave owns its row tiles, so there is nothing to share through LDS), 16 bytes per lane and step and tile.  With one
+// wave per SIMD nothing hides a load but the wave's own MFMAs, so the fragments ride a register ring AD steps deep, and the ring
+// never drains: a layer's steps form ONE sequence — gate conv (NSL slabs x KD taps), then res_skip (NSL slabs), then the NEXT
+// layer's gate conv — and step p's slot is refilled with step p + AD of that sequence, across the phase and layer boundaries (the
+// layer body is fully unrolled, S + NSL steps, a multiple of AD: slot indices are compile-time).  First version: look-ahead ONE step,
+// 120 us per block launch — every step waited an L2 round trip.  Biases come from LDS (staged once): a global load at a phase's
+// start would sit in the in-order load counter behind the ring and drain it.
+template <int KD, int NOCT, int MTW, int AD>
 __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
   constexpr int H = NOCT * 8;
   constexpr int MT = NOCT / 2;    // 32-row tiles of a 2H-row conv
@@ -46,9 +79,13 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
   constexpr int NSL = NOCT / 2;   // 16-channel slabs of the input
   constexpr int PADC = (KD - 1) / 2;
   constexpr int HW = WN_W + 2 * PADC;  // h tile row: the computed columns + the conv's reach (zeros) on either side
+  constexpr int S = NSL * KD;          // steps of a gate conv
+  constexpr int LS = S + NSL;          // steps of a whole layer
   static_assert(NOCT % 4 == 0 && MTW * 4 >= MT, "tile bookkeeping");
+  static_assert(AD <= S, "the look-ahead reaches at most into the next layer's gate conv");
   __shared__ uint4 hs[NOCT * HW];    // hidden state, fp16 octet rows
   __shared__ uint4 as[NOCT * WN_W];  // gated activations of the running layer
+  __shared__ float bs[WN_MAX_LAYERS * 2 * MT * 32];  // biases: [layer][gate | res_skip][virtual row]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -60,23 +97,7 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
   if (t0 >= L) return;
   const int c_abs0 = t0 - a.margin;  // column of tile column 0
   const float* hb = a.h + (long long)b * a.bs;
-
-  // ---- stage h: f32 rows -> fp16 octet units, zero outside the sequence; the pad columns are zeros
-  for (int u = tid; u < NOCT * WN_W; u += 256) {
-    const int o = u / WN_W, c = u - o * WN_W;
-    const int col = c_abs0 + c;
-    const bool ok = col >= 0 && col < L;
-    const int cc = ok ? col : 0;
-    half8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (_Float16)(ok ? hb[(long long)(8 * o + e) * a.ld + cc] : 0.f);
-    hs[o * HW + c + PADC] = __builtin_bit_cast(uint4, v);
-  }
-  for (int u = tid; u < NOCT * 2 * PADC; u += 256) {
-    const int o = u / (2 * PADC), p = u - o * (2 * PADC);
-    hs[o * HW + (p < PADC ? p : WN_W + p)] = uint4{0u, 0u, 0u, 0u};
-  }
-  __syncthreads();
+  const int n_layers = a.n_layers;
 
   const int col = lane & 31;
   const int hi = lane >> 5;
@@ -84,10 +105,62 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
   auto aload = [&](const uint4* base, int soff) -> uint4 {  // scalar base + the lane's constant byte offset (conv_f16.h)
     return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + soff) + lane16);
   };
-  auto bias_init = [&](floatx16 (&acc)[2], const float* bias, int mt) {
+  int mt[MTW], mtc[MTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    mt[i] = wave + 4 * i;
+    mtc[i] = mt[i] < MT ? mt[i] : MT - 1;  // a wave without an i-th tile recomputes the last one and stores nothing
+  }
+  // the layer's step sequence: p < S gate conv step (slab p / KD, tap p % KD); p < LS res_skip slab p - S; beyond: the next layer's gate
+  uint4 Af[AD + 1][MTW];
+  auto afetch = [&](int p, const uint4* wg, const uint4* wr, const uint4* wn, uint4 (&af)[MTW]) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (p < S)
+        af[i] = aload(wg, mtc[i] * (NSL * KD * 64) + p * 64);  // [m-tile][slab][tap][lane]: step p = slab * KD + tap
+      else if (p < LS)
+        af[i] = aload(wr, mtc[i] * (NSL * 64) + (p - S) * 64);
+      else
+        af[i] = aload(wn, mtc[i] * (NSL * KD * 64) + (p - LS) * 64);
+    }
+  };
+  // the ring's first AD steps go out before anything else: they fly while h is staged
+#pragma unroll
+  for (int p = 0; p < AD; ++p) afetch(p, a.w_in[0], a.w_in[0], a.w_in[0], Af[p]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- stage h: f32 rows -> fp16 octet units, zero outside the sequence; the pad columns are zeros; the biases
+  static_assert((NOCT * WN_W) % 256 == 0, "whole sweeps of the 256 threads");
+#pragma unroll 2
+  for (int u = tid; u < NOCT * WN_W; u += 256) {  // clamped addresses, nothing behind a branch: a unit's eight loads fly together
+    const int o = u / WN_W, c = u - o * WN_W;
+    const int cl = c_abs0 + c;
+    const bool ok = cl >= 0 && cl < L;
+    const float* src = hb + (long long)(8 * o) * a.ld + (ok ? cl : 0);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = src[(long long)e * a.ld];
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)(ok ? f[e] : 0.f);
+    hs[o * HW + c + PADC] = __builtin_bit_cast(uint4, v);
+  }
+  for (int u = tid; u < NOCT * 2 * PADC; u += 256) {
+    const int o = u / (2 * PADC), p = u - o * (2 * PADC);
+    hs[o * HW + (p < PADC ? p : WN_W + p)] = uint4{0u, 0u, 0u, 0u};
+  }
+  for (int u = tid; u < n_layers * 2 * MT * 32; u += 256) {
+    const int j = u / (2 * MT * 32), r = u - j * (2 * MT * 32);
+    const bool rs = r >= MT * 32;
+    const float* src = rs ? (j < n_layers - 1 ? a.b_rs[j] + (r - MT * 32) : a.b_in[j]) : a.b_in[j] + r;
+    bs[u] = *src;  // (the last layer has no res_skip here: its slot is never read)
+  }
+  __syncthreads();
+
+  auto bias_init = [&](floatx16 (&acc)[2], const float* bias) {  // bias: the tile's 32 rows in LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + mt * 32 + 8 * j + 4 * hi);
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + 8 * j + 4 * hi);
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         acc[nb][4 * j + 0] = b4.x;
@@ -99,50 +172,51 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
   };
 
   floatx16 acc[MTW][2];  // the running contraction of this wave's tiles x the tile's two column blocks
-  floatx16 sk[MTW][2];   // skip sums of the tiles that are skip rows (f32 across the layers)
+  // skip sums of the tiles that are skip rows (f32 across the layers).  Tile i of wave w is row tile w + 4 i: the tiles i < SK0 are
+  // res rows on every wave and carry no sum
+  constexpr int SK0 = NRES / 4;
+  floatx16 sk[MTW - SK0][2];
 #pragma unroll
-  for (int i = 0; i < MTW; ++i)
+  for (int i = 0; i < MTW - SK0; ++i)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sk[i][nb][r] = 0.f;
 
-  for (int j = 0; j < a.n_layers; ++j) {
-    const bool last = j == a.n_layers - 1;
+  for (int j = 0; j < n_layers; ++j) {
+    const bool last = j == n_layers - 1;
+    // the sequence's pointers; past the last layer's gate conv the ring is refilled from addresses nobody uses (no load behind a branch)
+    const uint4* wg = a.w_in[j];
+    const uint4* wr = last ? wg : a.w_rs[j];
+    const uint4* wn = last ? wg : a.w_in[j + 1];
     // ---- gate conv: 2H rows (paired), K-dim = (slab, tap); B fragments at any tap offset are one aligned ds_read_b128
-    int mt[MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      mt[i] = wave + 4 * i;
-      bias_init(acc[i], a.b_in[j], mt[i] < MT ? mt[i] : MT - 1);
-    }
+    for (int i = 0; i < MTW; ++i) bias_init(acc[i], bs + (j * 2 * MT + mtc[i]) * 32);
     {
-      const uint4* wj = a.w_in[j];
-      constexpr int S = NSL * KD;
-      uint4 Af[2][MTW], Bf[2][2];
-      auto fetch = [&](int g, uint4 (&af)[MTW], uint4 (&bf)[2]) {
-        g = g < S ? g : S - 1;
+      uint4 Bf[2][2];
+      auto bfetch = [&](int g, uint4 (&bf)[2]) {
         const int s = g / KD, k = g - s * KD;
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) af[i] = aload(wj, (((mt[i] < MT ? mt[i] : MT - 1) * NSL + s) * KD + k) * 64);
         const uint4* bp = hs + (2 * s + hi) * HW + col + k;
         bf[0] = bp[0];
         bf[1] = bp[32];
       };
-      fetch(0, Af[0], Bf[0]);
-      for (int g = 0; g < S; g += 2) {
-        fetch(g + 1, Af[1], Bf[1]);
+      bfetch(0, Bf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < S; ++g) {
+        afetch(g + AD, wg, wr, wn, Af[AD]);
+        bfetch(g + 1 < S ? g + 1 : g, Bf[1]);
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) acc[i][nb] = mfma_f16(Af[0][i], Bf[0][nb], acc[i][nb]);
-        fetch(g + 2, Af[0], Bf[0]);
-        if (g + 1 < S) {
+        WN_STEP_ORDER();
 #pragma unroll
-          for (int i = 0; i < MTW; ++i)
+        for (int d = 0; d < AD; ++d)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[i][nb] = mfma_f16(Af[1][i], Bf[1][nb], acc[i][nb]);
-        }
+          for (int i = 0; i < MTW; ++i) Af[d][i] = Af[d + 1][i];
+        Bf[0][0] = Bf[1][0];
+        Bf[0][1] = Bf[1][1];
       }
     }
     // gate: rows 0 .. 15 of a tile are tanh rows, 16 .. 31 the sigmoid rows of the same channels: accumulator registers r and r + 8
@@ -156,12 +230,7 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
         for (int jj = 0; jj < 2; ++jj) {
           float g4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float ta = acc[i][nb][4 * jj + e], sb = acc[i][nb][8 + 4 * jj + e];
-            const float th = 2.0f / (1.0f + expf(-2.0f * ta)) - 1.0f;
-            const float sg = 1.0f / (1.0f + expf(-sb));
-            g4[e] = th * sg;
-          }
+          for (int e = 0; e < 4; ++e) g4[e] = gate_fast(acc[i][nb][4 * jj + e], acc[i][nb][8 + 4 * jj + e]);
           if (!last) {
             half4 hv;
 #pragma unroll
@@ -182,32 +251,31 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
     __syncthreads();  // the gated tile is complete; every wave has read its last h fragment
     // ---- res_skip 1 x 1: 2H rows in natural order over the gated tile
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) bias_init(acc[i], a.b_rs[j], mt[i] < MT ? mt[i] : MT - 1);
+    for (int i = 0; i < MTW; ++i) bias_init(acc[i], bs + ((j * 2 + 1) * MT + mtc[i]) * 32);
     {
-      const uint4* wj = a.w_rs[j];
-      uint4 Af[2][MTW], Bf[2][2];
-      auto fetch = [&](int s, uint4 (&af)[MTW], uint4 (&bf)[2]) {
-        s = s < NSL ? s : NSL - 1;
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) af[i] = aload(wj, ((mt[i] < MT ? mt[i] : MT - 1) * NSL + s) * 64);
+      uint4 Bf[2][2];
+      auto bfetch = [&](int s, uint4 (&bf)[2]) {
         const uint4* bp = as + (2 * s + hi) * WN_W + col;
         bf[0] = bp[0];
         bf[1] = bp[32];
       };
-      fetch(0, Af[0], Bf[0]);
-      for (int s = 0; s < NSL; s += 2) {
-        fetch(s + 1, Af[1], Bf[1]);
+      bfetch(0, Bf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        afetch(S + s + AD, wg, wr, wn, Af[AD]);
+        bfetch(s + 1 < NSL ? s + 1 : s, Bf[1]);
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) acc[i][nb] = mfma_f16(Af[0][i], Bf[0][nb], acc[i][nb]);
-        fetch(s + 2, Af[0], Bf[0]);
-        if (s + 1 < NSL) {
+        WN_STEP_ORDER();
 #pragma unroll
-          for (int i = 0; i < MTW; ++i)
+        for (int d = 0; d < AD; ++d)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[i][nb] = mfma_f16(Af[1][i], Bf[1][nb], acc[i][nb]);
-        }
+          for (int i = 0; i < MTW; ++i) Af[d][i] = Af[d + 1][i];
+        Bf[0][0] = Bf[1][0];
+        Bf[0][1] = Bf[1][1];
       }
     }
 #pragma unroll
@@ -229,19 +297,19 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
             *hp = __builtin_bit_cast(uint2, hn);
           }
         }
-      } else {  // skip rows: summed in f32 across the layers
+      } else if (i >= SK0) {  // skip rows: summed in f32 across the layers
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sk[i][nb][r] += acc[i][nb][r];
+          for (int r = 0; r < 16; ++r) sk[i - SK0][nb][r] += acc[i][nb][r];
       }
     }
     __syncthreads();  // h is updated before the next layer's gate conv reads it
   }
 
-  if (a.n_layers > 1) {
+  if (n_layers > 1) {
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
+    for (int i = SK0; i < MTW; ++i) {
       const int t = wave + 4 * i;
       if (t < NRES || t >= MT) continue;
 #pragma unroll
@@ -253,7 +321,7 @@ __global__ __launch_bounds__(256) void wn_f16_kernel(const WnF16Args a) {
         for (int jq = 0; jq < 4; ++jq) {
           float* dst = a.skip + (long long)b * a.bs + (long long)(32 * (t - NRES) + 8 * jq + 4 * hi) * a.ld + ca;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst[(long long)e * a.ld] = sk[i][nb][4 * jq + e];
+          for (int e = 0; e < 4; ++e) dst[(long long)e * a.ld] = sk[i - SK0][nb][4 * jq + e];
         }
       }
     }

@@ -316,6 +316,8 @@ inline u32x2_emu permlane32_swap(uint32_t old_v, uint32_t src_v) {
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 // only ever applied to wave-uniform values in csrc/ (it tells the compiler they ARE uniform)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
