@@ -23,14 +23,14 @@ enum KName {
   KN_CONV_MFMA = 0, KN_CONV_M128, KN_CONV_GROUP, KN_RB_CONV, KN_RB_GROUP, KN_RB_GROUP_SNAKE, KN_PAIR, KN_PAIR_GROUP, KN_RB_PAIR,
   KN_RB_PAIR_GROUP, KN_CONV_BF16, KN_CONV_BF16_GROUP, KN_PAIR_BF16, KN_PAIR_BF16_GROUP, KN_MRF_SMALL, KN_MRF8, KN_GATE16, KN_GATE16_WIDE, KN_LIN16,
   KN_LIN16_LN, KN_LIN16_WIDE, KN_GLOW_TAIL, KN_OPROJ_LN, KN_POST_CONV, KN_WAVE_OUT, KN_ATTENTION, KN_CONV_F16, KN_CONV_F16_GROUP, KN_POST_F16,
-  KN_PACK_OCTETS, KN_PAIR_F16_GROUP, KN_WN_F16, KN_COUNT
+  KN_PACK_OCTETS, KN_PAIR_F16_GROUP, KN_WN_F16, KN_RB_GROUP_NB4, KN_COUNT
 };
 static const char* kname_name[KN_COUNT] = {
     "conv_mfma_kernel", "conv_mfma_kernel.m128", "conv_group_kernel", "rb_conv_kernel", "rb_group_kernel", "rb_group_kernel.snake",
     "resblock_pair_kernel", "pair_group_kernel", "rb_pair_kernel", "rb_pair_group_kernel", "conv_bf16_kernel", "conv_bf16_group_kernel",
     "pair_bf16_kernel", "pair_bf16_group_kernel", "mrf_small_kernel", "mrf8_kernel", "gate16_kernel", "gate16_kernel.wide", "lin16_kernel", "lin16_kernel.ln", "lin16_kernel.wide",
     "glow_tail_kernel", "oproj_ln_kernel", "post_conv_kernel", "wave_out_kernel", "attention_mfma_kernel", "conv_f16_kernel", "conv_f16_group_kernel",
-    "post_f16_kernel", "pack_octets_kernel", "pair_f16_group_kernel", "wn_f16_kernel"};
+    "post_f16_kernel", "pack_octets_kernel", "pair_f16_group_kernel", "wn_f16_kernel", "rb_group_kernel.nb4"};
 // the launch helpers without a context argument (launch_conv_k, launch_group_k) count through this: set by run_plan / run_group
 static thread_local std::atomic<long long>* g_kn = nullptr;
 // the kernel name (and launch sub-key: output rows / channels) of the launch inside the running ProfScope: the scope's

@@ -557,6 +557,32 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
     for (int i = 0; i < 3; ++i) rb_ok = rb_ok && rb_member_ok(g.c[i], i == 0 ? 11 : i == 1 ? 7 : 3);
     if (rb_ok) {
       static const bool no_snake = [] { const char* e = std::getenv("MI355TTS_NO_SNAKE"); return e && std::atoi(e) != 0; }();
+      // 128-column tiles (NB = 4: half the weight-fragment bytes and staged halo per MFMA, three workgroups per CU) when the launch
+      // still more than fills the chip with them.  Same chains per output element: same bits.
+      // Measured A B A B (profiles/r06_nb4_ab.txt): the 128-channel stage's launch alone 240 -> 250 us (927 workgroups deal worse over
+      // 768 slots than 1851 over 1024), 8 calls in flight +0.8-1.1 % utterances/s; the 256-channel stage (234 workgroups) -1.6 % — so
+      // only launches with more 128-column tiles than the chip holds at once take them (the dispatcher then balances by itself).
+      // MI355TTS_RB_NB4_MIN_TILES = threshold, 0 = never.
+      const char* nb4_env = std::getenv("MI355TTS_RB_NB4_MIN_TILES");  // (read per launch, like MI355TTS_GROUP_NCU: tests move it)
+      const int nb4_min = nb4_env ? std::atoi(nb4_env) : 3 * ncu;
+      if (nb4_min > 0 && grid.z == 1) {
+        int tiles4 = 0;
+        for (int i = 0; i < 3; ++i) tiles4 += ((plans[ord[i]].n_max + 127) / 128) * g.gy[i];
+        if (tiles4 >= nb4_min) {
+          int o4 = 0;
+          for (int i = 0; i < 3; ++i) {
+            g.gx[i] = (plans[ord[i]].n_max + 127) / 128;
+            g.off[i] = o4;
+            o4 += (g.gx[i] * g.gy[i] + 7) & ~7;
+          }
+          g.off[3] = o4;
+          const dim3 grid4(o4, 1, 1);
+          if (!no_snake && w->o_snake) group_snake_order(g, ncu, 3 * ncu);
+          kn_add(KN_RB_GROUP_NB4);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3, 4>), grid4, dim3(256), 0, s, g);
+          return 0;
+        }
+      }
       if (grid.z == 1 && !no_snake && w->o_snake) group_snake_order(g, ncu, 4 * ncu);  // four of these workgroups fit a CU (32 KB, <= 128 VGPRs)
       kn_add(g.nseg ? KN_RB_GROUP_SNAKE : KN_RB_GROUP);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_group_kernel<11, 7, 3>), grid, dim3(256), 0, s, g);

@@ -316,18 +316,20 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
   float bb[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bb[r] = (RB_ABL & 16) ? 0.01f : a.bias[row0 + (r & 3) + 8 * (r >> 2)];  // packed bias: padded to whole m-tiles, never null here
-  if (interior && NB == 2 && RB_WIDE_STORES && (a.y_ld & 3) == 0) {
+  if (interior && NB % 2 == 0 && RB_WIDE_STORES && (a.y_ld & 3) == 0) {
     // Interior tiles: the accumulator blocks go through LDS once ([32 rows][64 columns] per wave, over the dead ring) so that
     // a lane holds FOUR consecutive columns: 8 dwordx4 residual loads + 8 dwordx4 stores per lane instead of 32 + 32 dword ones
     // (the epilogue of such a tile is store-ISSUE-bound: MI355X_MICROARCH.md).  Same arithmetic: (acc + bias) + residual.
     __syncthreads();  // every wave has issued its last operand read of the ring
     float* tw = xs + wm * (32 * 64);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + rbase) * 64 + nb * 32 + col] = acc[nb][r] + bb[r];
-    __builtin_amdgcn_wave_barrier();  // no instruction: LDS operations of one wave execute in order, its reads below see its writes
     const int rbase0 = mt0 * 32;
+#pragma unroll
+    for (int np = 0; np < NB / 2; ++np) {  // 64 columns at a time (NB = 4: the wave's 8 KB twice; its LDS operations execute in order)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + rbase) * 64 + nb * 32 + col] = acc[2 * np + nb][r] + bb[r];
+    __builtin_amdgcn_wave_barrier();  // no instruction: LDS operations of one wave execute in order, its reads below see its writes
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float4 v[4], rv[4];
@@ -336,7 +338,7 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
       for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * (4 * h + i);
         const int row = idx >> 4, c4 = idx & 15;
-        off[i] = (rbase0 + row) * a.y_ld + t0 + 4 * c4;
+        off[i] = (rbase0 + row) * a.y_ld + t0 + 64 * np + 4 * c4;
         v[i] = *reinterpret_cast<const float4*>(tw + row * 64 + 4 * c4);
       }
       if (rb && !(RB_ABL & 16)) {
@@ -352,6 +354,8 @@ __device__ __forceinline__ void rb_tile(const ConvArgs& a, const int tile_x, con
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(yb + off[i]) = v[i];
+    }
+    if (np + 1 < NB / 2) __builtin_amdgcn_wave_barrier();
     }
   } else if (interior) {
     const int o0 = row0 * a.y_ld + t0 + col;  // a plane of one batch row is < 2^31 floats (conv_tile indexes it the same way)
@@ -429,7 +433,7 @@ template <> struct RbCfg<3> { static constexpr int HALO = 16; };
 
 // the three MRF chains' same-geometry convs in one launch, longest first (cf. conv_group_kernel)
 template <int K0, int K1, int K2, int NB = 2>
-__global__ __launch_bounds__(256, 4) void rb_group_kernel(const ConvGroupArgs g) {
+__global__ __launch_bounds__(256, NB > 2 ? 3 : 4) void rb_group_kernel(const ConvGroupArgs g) {
   constexpr int H0 = RbCfg<K0>::HALO, H1 = RbCfg<K1>::HALO, H2 = RbCfg<K2>::HALO;
   constexpr int L0 = rb_lds_floats<H0, NB>(), L1 = rb_lds_floats<H1, NB>(), L2 = rb_lds_floats<H2, NB>();
   __shared__ float xs[L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2)];

@@ -526,6 +526,37 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
         emu_engine.unload(v)
 
 
+def test_128_column_tiles_of_the_one_row_tile_stage_give_the_same_bits(emu_engine, monkeypatch):
+    """A grouped launch of the 128-channel stage with more 128-column tiles than the chip holds at once (3 workgroups per CU)
+    runs `rb_group_kernel<11, 7, 3, 4>` — four column blocks per wave, the interior tiles' 16-byte epilogue in two passes of 64
+    columns: the same chain per output element, so the same bits as the 64-column tile.  `MI355TTS_GROUP_NCU` = 8 puts the
+    threshold at 24 tiles; 1010 columns = 8 tiles per member, the last one an edge tile (114 of 128 columns)."""
+    hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
+                           resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 5), (1, 3), (1, 5)), num_mels=16)
+    sd = synthetic.make_hifigan_state_dict(hp, seed=96)
+    v = emu_engine.load_hifigan(hp, sd)
+    try:
+        mel = (0.5 + 0.1 * np.random.default_rng(15).standard_normal((1, hp.num_mels, 505))).astype(np.float32)
+        mb = emu_engine.mel_from_numpy(mel)
+        monkeypatch.setenv("MI355TTS_M128_MIN_TILES", "1")
+        monkeypatch.setenv("MI355TTS_GROUP_NCU", "8")
+        monkeypatch.setenv("MI355TTS_RB_NB4_MIN_TILES", "0")
+        narrow, _ = emu_engine.hifigan_infer(v, mb)
+        monkeypatch.delenv("MI355TTS_RB_NB4_MIN_TILES")  # the default threshold: 3 x 8 = 24 tiles
+        emu_engine.profile_reset()
+        wide, _ = emu_engine.hifigan_infer(v, mb)
+        counts = emu_engine.kernel_counts()
+        assert counts.get("rb_group_kernel.nb4", 0) == 2 * 2 and counts.get("rb_group_kernel", 0) + counts.get("rb_group_kernel.snake", 0) == 0, counts
+        monkeypatch.setenv("MI355TTS_RB_NB4_MIN_TILES", "25")  # one more than the launch has: the 64-column tile again
+        again, _ = emu_engine.hifigan_infer(v, mb)
+        assert np.isfinite(wide).all() and np.abs(wide).max() > 1e-3
+        assert np.array_equal(wide, narrow) and np.array_equal(again, narrow)
+        ref = hifi_gan_np.hifigan_infer(sd, hp, mel[0])
+        assert np.sqrt(np.mean((wide[0, : ref.shape[0]] - ref) ** 2)) < 1e-5
+    finally:
+        emu_engine.unload(v)
+
+
 def test_four_wave_pair_kernel_against_the_k_split_one(emu_engine, monkeypatch):
     """`rb_pair_kernel` / `rb_pair_group_kernel` (rb_pair.h: 4 waves, no k-split, the parked conv1 tile over the x tile) run the
     fused ResBlock steps of the 64- / 32-channel stages by default; option "rb_pair" = 0 sends them to the 8-wave k-split

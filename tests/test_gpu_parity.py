@@ -377,9 +377,10 @@ def test_glowtts_launch_counts_on_the_device(gpu_engine):
 
 VOC_KERNELS = {
     # 'high' at 617 frames, batch 1: the 256-channel stage's six launches are the PROMOTED ones (128-row tile, snake dispatch
-    # order), the 128-channel stage's six keep the plain longest-first order (more workgroups than resident slots), the 64- and
-    # 32-channel stages run the four-wave fused pair; nothing falls back to the chunked tile or the k-split pair
-    "high": {"rb_group_kernel.snake": 6, "rb_group_kernel": 6, "rb_pair_group_kernel": 6, "conv_group_kernel": 0, "pair_group_kernel": 0,
+    # order), the 128-channel stage's six run 128-column tiles in the plain longest-first order (927 of them: more than the 768
+    # the chip holds at once — host_launch.h, run_group), the 64- and 32-channel stages run the four-wave fused pair; nothing falls
+    # back to the chunked tile or the k-split pair
+    "high": {"rb_group_kernel.snake": 6, "rb_group_kernel.nb4": 6, "rb_group_kernel": 0, "rb_pair_group_kernel": 6, "conv_group_kernel": 0, "pair_group_kernel": 0,
              "mrf_small_kernel": 0, "mrf8_kernel": 0},
     # 'medium': 42 / 161 tiles per member in its 64- / 32-channel stages -> the 8-wave k-split pair (plan_pair's rule); the 16-
     # and 8-channel stages are one launch each

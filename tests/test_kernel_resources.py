@@ -146,7 +146,7 @@ def test_round5_kernels(resources):
 
 def test_continuous_stream_tile_resources(resources):
     """rb_group_kernel (rb_conv.h): four 4-wave workgroups per CU by registers (<= 128, no scratch), 32 KB of LDS each."""
-    rb = {n: r for n, r in resources.items() if "rb_group_kernel" in n}
+    rb = {n: r for n, r in resources.items() if "rb_group_kernelILi11ELi7ELi3ELi2E" in n}  # (the 128-column variant: test_round6_late_kernels)
     assert len(rb) == 1, sorted(rb)
     for n, r in rb.items():
         assert r["vgprs"] <= 128 and r["scratch"] == 0 and r["lds"] == 32 * 1024 and r["occupancy"] >= 4, (n, r)
@@ -206,3 +206,18 @@ def test_fp16_mode_kernels(resources):
     for n, r in f16.items():
         if "conv_f16" in n:
             assert r["occupancy"] >= 2 and r["lds"] <= 42 * 1024, (n, r)
+
+
+def test_round6_late_kernels(resources):
+    """`wn_f16_kernel` (wn_f16.h: a coupling block's WaveNet as one fp16 launch): one wave per SIMD by design — the whole register
+    file of a wave is its accumulators (96) + skip sums (64) + a 10-step weight ring (120) — and NO scratch: a spilled ring slot
+    would put a scratch round trip into every step; 76 KB of LDS (h + gated tile + biases) at H = 192.  `rb_group_kernel<11, 7, 3, 4>`
+    (rb_conv.h, 128-column tiles of the 128-channel stage): three workgroups per CU (<= 168 VGPRs, 48 KB), no scratch."""
+    wn = {n: r for n, r in resources.items() if "wn_f16_kernel" in n}
+    assert len(wn) == 2, sorted(wn)
+    for n, r in wn.items():
+        assert r["scratch"] == 0 and r["lds"] <= 76 * 1024, (n, r)
+    nb4 = {n: r for n, r in resources.items() if re.search(r"rb_group_kernelILi11ELi7ELi3ELi4E", n)}
+    assert len(nb4) == 1, sorted(nb4)
+    for n, r in nb4.items():
+        assert r["scratch"] == 0 and r["vgprs"] <= 168 and r["occupancy"] >= 3 and r["lds"] <= 48 * 1024, (n, r)
