@@ -43,7 +43,7 @@ sys.path.insert(0, str(REPO))
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, f32 MFMA = f32 vector peak
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 SAMPLE_RATE = 22050
-ROUND = "r05"
+ROUND = "r06"
 
 
 def algorithmic_flop(P: int, F: float, quality: str = "high") -> float:
@@ -566,12 +566,13 @@ def main():
     g = eng.load_glow(ghp, device_ptr=blob.data_ptr())
     v = eng.load_hifigan(vhp, device_ptr=blob.data_ptr() + 4 * n_g)
     del blob
+    glow_f16_line = False  # --precision f16: the acoustic model's decoder WaveNets in fp16 too
     if args.precision == "bf16x3":
         eng.set_precision(v, ffi.PRECISION_BF16X3)
     elif args.precision == "f16":
         eng.set_precision(v, ffi.PRECISION_F16)
         if args.half_acoustic == "f16":
-            eng.set_precision(g, ffi.PRECISION_F16)
+            glow_f16_line = eng.set_precision(g, ffi.PRECISION_F16) == 0
 
     # ---- synthetic utterances (one per step per rank), resident in HBM
     rng = np.random.default_rng(1234 + rank)
@@ -1030,7 +1031,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f16 (fp16 planes and weights, f32 accumulate) in the whole vocoder, f32 in GlowTTS",
+            "dtype": {"f32": "f32", "f16": "f16 (fp16 planes and weights, f32 accumulate) in the whole vocoder"
+                                            + (" and in the WaveNets of GlowTTS' decoder (wn_f16.h), f32 in the rest of GlowTTS" if glow_f16_line else ", f32 in GlowTTS"),
                       "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate) in the ResBlock convs and upsamplers, f32 elsewhere"}[args.precision],
             "data": "synthetic",
             "config": {
@@ -1183,6 +1185,20 @@ def main():
             "profile_ms_per_step": {k_: v_["ms"] / K for k_, v_ in prof.items()},
         }
         out["roofline"]["by_kernel"] = by_kernel_table(prof_kernels)
+        if args.precision != "f32":
+            # the reduced modes as the line's own subject: price the class against the 16-bit matrix peak — per USEFUL product (fp16: one
+            # MFMA per product; bf16x3 executes three), and no committed PMC traffic for these kernels
+            rf = out["roofline"]
+            rf["kernel"] = ("HiFi-GAN ResBlock launches in the fp16 mode: pair_f16_group_kernel (fused conv1 + conv2 of a step, 128 / 64 / 32 channels), "
+                            "conv_f16_group_kernel (256 channels)" if args.precision == "f16" else
+                            "HiFi-GAN ResBlock launches in the split-bf16 mode: conv_bf16_group_kernel / pair_bf16_group_kernel (three bf16 MFMAs per product)")
+            rf["peak"] = BF16_PEAK_TFLOPS
+            rf["frac"] = dom_tf_raw / BF16_PEAK_TFLOPS
+            rf["frac_minus_event_overhead"] = dom_tf / BF16_PEAK_TFLOPS
+            rf["frac_note"] = "achieved = algorithmic f32-path FLOPs / time, priced against the dense 16-bit MFMA peak (2.5 PFLOP/s): per useful product"
+            rf["traffic"] = None
+            rf["traffic_source"] = "no committed PMC passes for this mode's kernels"
+            rf["algorithmic_bytes_per_launch"] = "half the f32 figure in the fp16 mode (fp16 planes), conv1's plane never leaves LDS in the fused launches"
         if c3 is not None:
             out["config3"] = c3
         if c4 is not None:
