@@ -457,6 +457,9 @@ def main():
     ap.add_argument("--library", default=os.environ.get("MI355TTS_LIB"), help="alternative libmi355tts build (A/B runs, emulator)")
     ap.add_argument("--tiny", action="store_true", help="shrunk hyper-parameters (emulator runs)")
     ap.add_argument("--tiny-half", action="store_true", help="with --tiny: run the half-mode (fp16) and split-bf16 legs too (they are skipped on the emulator by default)")
+    ap.add_argument("--acoustic-f16", action="store_true",
+                    help="probe: with --precision f32, the acoustic model's decoder WaveNets in fp16 (csrc/wn_f16.h) in front of the exact f32 "
+                         "vocoder; implies --no-half-mode.  NOT the headline's configuration: the line's dtype says so")
     ap.add_argument("--half-acoustic", default="f16", choices=["f16", "f32"],
                     help="the acoustic model in the fp16 mode (half_mode leg, --precision f16): f16 = the decoder's WaveNets in fp16 "
                          "(csrc/wn_f16.h), f32 = only the vocoder takes the switch")
@@ -567,6 +570,8 @@ def main():
     v = eng.load_hifigan(vhp, device_ptr=blob.data_ptr() + 4 * n_g)
     del blob
     glow_f16_line = False  # --precision f16: the acoustic model's decoder WaveNets in fp16 too
+    if args.precision == "f32" and args.acoustic_f16:  # probe: exact f32 vocoder behind the fp16 acoustic mode (NOT the headline's configuration)
+        glow_f16_line = eng.set_precision(g, ffi.PRECISION_F16) == 0
     if args.precision == "bf16x3":
         eng.set_precision(v, ffi.PRECISION_BF16X3)
     elif args.precision == "f16":
@@ -816,7 +821,7 @@ def main():
     half = None
     x3_flight = 0.0
     glow_f16 = False
-    if args.precision == "f32" and (not args.tiny or args.tiny_half) and not args.no_half_mode:
+    if args.precision == "f32" and (not args.tiny or args.tiny_half) and not args.no_half_mode and not args.acoustic_f16:
         eng.set_precision(v, ffi.PRECISION_F16)
         # `half` on the acoustic model: the decoder's WaveNets in fp16 (0), or a reported no-op on a geometry wn_f16.h does not cover
         glow_f16 = args.half_acoustic == "f16" and eng.set_precision(g, ffi.PRECISION_F16) == 0
@@ -1031,7 +1036,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f16 (fp16 planes and weights, f32 accumulate) in the whole vocoder"
+            "dtype": {"f32": "f32" if not glow_f16_line else "MIXED (probe, --acoustic-f16): f32 vocoder, fp16 WaveNets in GlowTTS' decoder (wn_f16.h), f32 elsewhere", "f16": "f16 (fp16 planes and weights, f32 accumulate) in the whole vocoder"
                                             + (" and in the WaveNets of GlowTTS' decoder (wn_f16.h), f32 in the rest of GlowTTS" if glow_f16_line else ", f32 in GlowTTS"),
                       "bf16x3": "bf16x3 (split-bf16 MFMA, f32 accumulate) in the ResBlock convs and upsamplers, f32 elsewhere"}[args.precision],
             "data": "synthetic",
