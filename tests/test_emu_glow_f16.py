@@ -105,6 +105,15 @@ def test_f16_request_is_a_reported_noop_where_the_kernel_does_not_cover_the_geom
         assert emu_engine.kernel_counts().get("wn_f16_kernel", 0) == 0
     finally:
         emu_engine.unload(g)
+    # speaker-conditioned WaveNets (cond_layer on every gate conv: glow_tts/layers.py:144-154) are not covered either
+    import dataclasses
+
+    hpm = dataclasses.replace(HP.TINY_GLOW, n_speakers=3, gin_channels=20)
+    gm = emu_engine.load_glow(hpm, synthetic.make_glow_state_dict(hpm, seed=75))
+    try:
+        assert emu_engine.set_precision(gm, ffi.PRECISION_F16) == ffi.PRECISION_NOOP
+    finally:
+        emu_engine.unload(gm)
     hp2 = _hp(32, 2, blocks=2)
     g2 = emu_engine.load_glow(hp2, synthetic.make_glow_state_dict(hp2, seed=75))
     try:

@@ -754,6 +754,39 @@ def test_f16_fused_call_against_the_reference(gpu_engine, name, acoustic):
     assert rms <= bar_rms and d16 <= bar_i16, (rms, d16)
 
 
+def test_f16_acoustic_config4_batch_rows(gpu_engine):
+    """BASELINE config 4's ragged batch of 8 (thorsten) with the acoustic model's decoder WaveNets in fp16: every row's frame count
+    the reference's, every row's mel within the reference's own decoder-under-.half() figures (the single-utterance thorsten case of
+    tests/golden/glow_half_reference.json: the same voice), padded tails exactly 0, and a row inside the batch equal to its solitary
+    call within a tenth of that figure (not bit for bit at this size: the f32 launches around the fp16 one pick other tiles for a
+    padded batch — another f32 summation order —, and the rounding of `h` to fp16 turns a last-bit difference into half an fp16 ulp
+    here and there; on the emulator's shapes, where the tiles coincide, rows equal their solitary calls exactly)."""
+    from larynx_amd import ffi
+    from tests.golden_util import load_batch8, load_glow_half_reference
+
+    c = load_batch8()
+    anchor = load_glow_half_reference()["thorsten_medium_veg"]
+    (gsd, g), _ = models(gpu_engine, c["glow_hp"], c["voc_hp"])
+    assert gpu_engine.set_precision(g, ffi.PRECISION_F16) == 0
+    try:
+        gpu_engine.profile_reset()
+        mel = gpu_engine.glow_infer(g, c["ids"], c["noise_scale"], c["length_scale"], noise=c["noise"])
+        assert gpu_engine.kernel_counts().get("wn_f16_kernel", 0) == c["glow_hp"].n_blocks_dec
+        raw = mel.numpy("raw")
+        for b in range(8):
+            F = c["mel"][b].shape[1]
+            assert int(mel.frames[b]) == F
+            d = raw[b][:, :F] - c["mel"][b]
+            assert float(np.abs(d).max()) <= anchor["dec_half_max"] and float(np.sqrt(np.mean(d ** 2))) <= anchor["dec_half_rms"], (b, float(np.abs(d).max()))
+            assert np.all(raw[b][:, F:] == 0)
+        for b in (0, 6):
+            one = gpu_engine.glow_infer(g, c["ids"][b], c["noise_scale"], c["length_scale"], noise=c["noise"][b])
+            F = int(one.frames[0])
+            assert float(np.abs(one.numpy("raw")[0][:, :F] - raw[b][:, :F]).max()) <= 0.1 * anchor["dec_half_max"]
+    finally:
+        gpu_engine.set_precision(g, ffi.PRECISION_F32)
+
+
 def test_f16_config4_batch_rows(gpu_engine):
     """BASELINE config 4 (thorsten + 'medium', B = 8 ragged) with the vocoder in fp16: every row within the reference's own
     .half() error for THAT row, padded tails exactly 0, and a row inside the batch equal to its solitary call bit for bit
