@@ -554,6 +554,19 @@ def test_shortest_utterances_full_size_models(gpu_engine, n_ids):
     wav, _ = gpu_engine.hifigan_infer(v, mel)
     refw = hifi_gan_np.hifigan_infer(vsd, HP.HIFIGAN_MEDIUM, audio_np.mel_to_vocoder_input(ref, s))
     assert np.sqrt(np.mean((wav[0] - refw) ** 2)) <= 1e-4
+    # the same ids with the decoder's WaveNets in fp16 (wn_f16.h: a one-tile launch with most of the tile past the sequence's end):
+    # same frame count, the mel inside the half-precision band the golden cases are held to (the reference's decoder under .half():
+    # 1.5-1.7e-3)
+    from larynx_amd import ffi
+
+    assert gpu_engine.set_precision(g, ffi.PRECISION_F16) == 0
+    try:
+        mel16 = gpu_engine.glow_infer(g, ids, 0.0, 1.0)
+    finally:
+        gpu_engine.set_precision(g, ffi.PRECISION_F32)
+    assert int(mel16.frames[0]) == ref.shape[1]
+    e16 = float(np.abs(mel16.numpy("raw")[0] - ref).max())
+    assert 0 < e16 <= 1.5e-3, e16
 
 
 @pytest.mark.parametrize("name", ["ljspeech_high_echo", "ljspeech_high_S120", "ljspeech_medium_dave_ls12", "ljspeech_low_echo"])
