@@ -561,10 +561,12 @@ static int run_group(mi355tts_ctx* ctx, Worker* w, const ConvPlan* plans, int n,
       // still more than fills the chip with them.  Same chains per output element: same bits.
       // Measured A B A B (profiles/r06_nb4_ab.txt): the 128-channel stage's launch alone 240 -> 250 us (927 workgroups deal worse over
       // 768 slots than 1851 over 1024), 8 calls in flight +0.8-1.1 % utterances/s; the 256-channel stage (234 workgroups) -1.6 % — so
-      // only launches with more 128-column tiles than the chip holds at once take them (the dispatcher then balances by itself).
-      // MI355TTS_RB_NB4_MIN_TILES = threshold, 0 = never.
+      // only launches with more 128-column tiles than the chip holds at once take them (the dispatcher then balances by itself), and
+      // only while ANOTHER call holds a worker of this context: a lone call keeps the 64-column tiles (its launch has the chip to
+      // itself and is 4 % faster on them).  The choice depends on the load, the result does not (same bits), like the dispatch order.
+      // MI355TTS_RB_NB4_MIN_TILES = threshold whatever the load (tests, A/B runs), 0 = never.
       const char* nb4_env = std::getenv("MI355TTS_RB_NB4_MIN_TILES");  // (read per launch, like MI355TTS_GROUP_NCU: tests move it)
-      const int nb4_min = nb4_env ? std::atoi(nb4_env) : 3 * ncu;
+      const int nb4_min = nb4_env ? std::atoi(nb4_env) : (ctx->active_calls.load(std::memory_order_relaxed) > 1 ? 3 * ncu : 0);
       if (nb4_min > 0 && grid.z == 1) {
         int tiles4 = 0;
         for (int i = 0; i < 3; ++i) tiles4 += ((plans[ord[i]].n_max + 127) / 128) * g.gy[i];

@@ -527,8 +527,8 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
 
 
 def test_128_column_tiles_of_the_one_row_tile_stage_give_the_same_bits(emu_engine, monkeypatch):
-    """A grouped launch of the 128-channel stage with more 128-column tiles than the chip holds at once (3 workgroups per CU)
-    runs `rb_group_kernel<11, 7, 3, 4>` — four column blocks per wave, the interior tiles' 16-byte epilogue in two passes of 64
+    """A grouped launch of the 128-channel stage with more 128-column tiles than the chip holds at once (3 workgroups per CU), issued
+    while another call is in flight (here: forced through `MI355TTS_RB_NB4_MIN_TILES`), runs `rb_group_kernel<11, 7, 3, 4>` — four column blocks per wave, the interior tiles' 16-byte epilogue in two passes of 64
     columns: the same chain per output element, so the same bits as the 64-column tile.  `MI355TTS_GROUP_NCU` = 8 puts the
     threshold at 24 tiles; 1010 columns = 8 tiles per member, the last one an edge tile (114 of 128 columns)."""
     hp = HP.HifiGanHParams(upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=256,
@@ -542,7 +542,7 @@ def test_128_column_tiles_of_the_one_row_tile_stage_give_the_same_bits(emu_engin
         monkeypatch.setenv("MI355TTS_GROUP_NCU", "8")
         monkeypatch.setenv("MI355TTS_RB_NB4_MIN_TILES", "0")
         narrow, _ = emu_engine.hifigan_infer(v, mb)
-        monkeypatch.delenv("MI355TTS_RB_NB4_MIN_TILES")  # the default threshold: 3 x 8 = 24 tiles
+        monkeypatch.setenv("MI355TTS_RB_NB4_MIN_TILES", "24")  # the default threshold of a busy context: 3 x 8 = 24 tiles
         emu_engine.profile_reset()
         wide, _ = emu_engine.hifigan_infer(v, mb)
         counts = emu_engine.kernel_counts()
@@ -551,6 +551,11 @@ def test_128_column_tiles_of_the_one_row_tile_stage_give_the_same_bits(emu_engin
         again, _ = emu_engine.hifigan_infer(v, mb)
         assert np.isfinite(wide).all() and np.abs(wide).max() > 1e-3
         assert np.array_equal(wide, narrow) and np.array_equal(again, narrow)
+        # without the variable the rule looks at the load: a lone call keeps the 64-column tiles (the launch has the chip to itself)
+        monkeypatch.delenv("MI355TTS_RB_NB4_MIN_TILES")
+        emu_engine.profile_reset()
+        lone, _ = emu_engine.hifigan_infer(v, mb)
+        assert emu_engine.kernel_counts().get("rb_group_kernel.nb4", 0) == 0 and np.array_equal(lone, narrow)
         ref = hifi_gan_np.hifigan_infer(sd, hp, mel[0])
         assert np.sqrt(np.mean((wide[0, : ref.shape[0]] - ref) ** 2)) < 1e-5
     finally:

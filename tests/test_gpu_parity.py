@@ -377,10 +377,10 @@ def test_glowtts_launch_counts_on_the_device(gpu_engine):
 
 VOC_KERNELS = {
     # 'high' at 617 frames, batch 1: the 256-channel stage's six launches are the PROMOTED ones (128-row tile, snake dispatch
-    # order), the 128-channel stage's six run 128-column tiles in the plain longest-first order (927 of them: more than the 768
-    # the chip holds at once — host_launch.h, run_group), the 64- and 32-channel stages run the four-wave fused pair; nothing falls
-    # back to the chunked tile or the k-split pair
-    "high": {"rb_group_kernel.snake": 6, "rb_group_kernel.nb4": 6, "rb_group_kernel": 0, "rb_pair_group_kernel": 6, "conv_group_kernel": 0, "pair_group_kernel": 0,
+    # order), the 128-channel stage's six keep the plain longest-first order (more workgroups than resident slots; a call that
+    # shares the context with another one runs them on 128-column tiles: test_busy_context_takes_128_column_tiles), the 64- and
+    # 32-channel stages run the four-wave fused pair; nothing falls back to the chunked tile or the k-split pair
+    "high": {"rb_group_kernel.snake": 6, "rb_group_kernel": 6, "rb_group_kernel.nb4": 0, "rb_pair_group_kernel": 6, "conv_group_kernel": 0, "pair_group_kernel": 0,
              "mrf_small_kernel": 0, "mrf8_kernel": 0},
     # 'medium': 42 / 161 tiles per member in its 64- / 32-channel stages -> the 8-wave k-split pair (plan_pair's rule); the 16-
     # and 8-channel stages are one launch each
@@ -415,6 +415,39 @@ def test_vocoder_launch_counts_on_the_device(gpu_engine, quality, resblock, narr
     assert prof["conv_mfma.hifigan_upsample"]["launches"] == 4 and prof["conv_mfma.hifigan_pre_post"]["launches"] == 2, prof
     for k, n in VOC_KERNELS[quality].items():
         assert names[k] == n, (k, names)
+
+
+def test_busy_context_takes_128_column_tiles(gpu_engine):
+    """`rb_group_kernel<11, 7, 3, 4>` (host_launch.h, run_group): the 128-channel stage's grouped launches of a call that shares the
+    context with another call run on 128-column tiles (927 of them at 617 frames: more than the chip holds) — the same bits as the lone
+    call's 64-column tiles.  Two threads synthesise the same mel concurrently; every result equals the lone call's, and the
+    128-column launches were taken (by some of the calls: a call that happens to find the context idle keeps the 64-column ones)."""
+    import threading
+
+    vhp = HP.VOCODER_QUALITY["high"]
+    _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, vhp)
+    mel = (0.57 + 0.06 * np.random.default_rng(5).standard_normal((1, 80, 617))).astype(np.float32)
+    lone, _ = gpu_engine.hifigan_infer(v, gpu_engine.mel_from_numpy(mel[0]))
+    gpu_engine.profile_reset()
+    out = [None] * 12
+    errs = []
+
+    def work(t):
+        try:
+            for i in range(t, len(out), 3):
+                out[i], _ = gpu_engine.hifigan_infer(v, gpu_engine.mel_from_numpy(mel[0]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    names = gpu_engine.kernel_counts()
+    assert names.get("rb_group_kernel.nb4", 0) > 0, names  # (read per launch: a call may mix the two tiles)
+    assert names.get("rb_group_kernel.nb4", 0) + names.get("rb_group_kernel", 0) == 6 * len(out), names
+    for w in out:
+        np.testing.assert_array_equal(w, lone)
 
 
 def test_dispatch_order_selfcheck_on_the_device(gpu_engine):
