@@ -285,6 +285,10 @@ int mi355tts_set_profiling(mi355tts_ctx* ctx, int enabled);
  *     the order does not win;
  *   "gate16_wide" (default 512) — gate convs / 1 x 1 convs of passes with at least this many 16-row tiles (padded batches) take
  *     two / four row tiles per workgroup from one staged input tile (0 = never).
+ *   Not an option, the same class: while ANOTHER call holds a worker of the context, a batch-1 grouped ResBlock launch with more
+ *     128-column tiles than the chip holds at once runs on them (rb_group_kernel<11, 7, 3, 4>) instead of on 64-column tiles — the
+ *     same chain per output element, so which one a call gets depends on the load and its result does not (environment
+ *     MI355TTS_RB_NB4_MIN_TILES pins the threshold whatever the load; 0 = never).
  * (2) Tile options: another tile = another f32 SUMMATION ORDER; results equal to f32 round-off, never changed by the library
  * itself (a timing never picks a tile):
  *   "gate16", "glow_fuse", "mrf_small" (0/1, default 1) — the small-launch kernels of gate16.h / coltile.h / mrf_small.h
