@@ -543,6 +543,14 @@ def main():
             dist.barrier()
         sync()
 
+    _dummy = []
+    if on_gpu and os.environ.get("BENCH_DUMMY_STREAMS"):  # probe: streams created (and used once) before the library's worker streams
+        for _ in range(int(os.environ["BENCH_DUMMY_STREAMS"])):
+            st = torch.cuda.Stream(device=local)
+            with torch.cuda.stream(st):
+                torch.zeros(64, device=f"cuda:{local}").add_(1.0)
+            _dummy.append(st)
+        torch.cuda.synchronize()
     eng = Engine(device=local if on_gpu else 0, library_path=args.library)
     for kv in args.set_option:
         eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -601,6 +609,7 @@ def main():
     # hipMalloc / hipFree / stream creation can happen inside a timed region
     dn_ok = 88 * hop > 1024  # the denoiser's 1024-point STFT needs a real vocoder hop (not the emulator's tiny one)
     eng.reserve(conc + 1, g, v, max_batch=B, max_ids=max(args.ids, 200), max_frames=max(max_frames, 2400), denoiser=dn_ok)
+    qgroups_headline = eng.worker_queue_groups()  # as the headline's calls find them (later legs reserve other worker counts)
     if B == 1 and conc > 1:
         # concurrent batch-1 calls may ride fused padded calls (csrc/host_join.h): any worker may lead a pass of up to `conc` rows
         eng.reserve(conc + 1, g, v, max_batch=conc, max_ids=max(args.ids, 200), max_frames=max_frames)
@@ -1156,6 +1165,9 @@ def main():
                 "note": "each rank's own median over the repeats; `value` = all ranks' utterances / the slowest rank's time",
             },
             "host_affinity_rank0": affinity,
+            # hardware-queue group of every worker stream as mi355tts_reserve measured it (creation order; a call takes the free
+            # worker whose queue carries the fewest calls: include/mi355tts.h, mi355tts_worker_queue_groups)
+            "worker_queue_groups_rank0": qgroups_headline,
             "process_group": (("nccl (RCCL)" if rccl else ("gloo" if not on_gpu else f"gloo (RCCL init failed: {pg_note}); every rank folded its own seeded weights")) if use_dist else None),
             "roofline": {
                 "kernel": "HiFi-GAN ResBlock launches: rb_group_kernel (256- and 128-channel stages: the continuous-stream tile of rb_conv.h; conv_group_kernel = the k-split tile at the utterance lengths the promotion rule leaves alone), rb_pair_group_kernel (fused conv pairs of the 64/32-channel stages on four waves, rb_pair.h)",

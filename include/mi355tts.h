@@ -240,6 +240,19 @@ int mi355tts_synthesize_speakers(mi355tts_ctx* ctx, int glow, int vocoder, const
  * be 0 to size for one model only. */
 int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vocoder, int max_batch, int max_ids, int max_frames,
                      int denoiser, int max_pad_samples);
+/* Measurement: the hardware-queue group of every worker of the context, in creation order (groups[i] for worker i; -1 = not probed:
+ * a worker created on demand after the last mi355tts_reserve).  The HIP runtime deals its few hardware queues (4) to streams as
+ * they are first used, and two streams of one queue run their kernels one after the other; mi355tts_reserve measures which of its
+ * worker streams share a queue (one kernel waits for a host flag on stream A while another raises a flag on stream B: if B's does
+ * not come up, B sits behind A) and a call then takes the free worker whose queue carries the fewest calls.  Which worker a call
+ * gets never changes its result.  Returns the number of workers (only `capacity` entries are written).  MI355TTS_NO_QUEUE_PROBE=1
+ * skips the measurement (every worker -1: the most recently released free worker is taken, as before round 6).
+ * MI355TTS_QUEUE_POLICY=1: an idle queue first, otherwise the BUSIEST one (as many calls as there are queues get a queue to
+ * themselves, the rest share one) instead of the least busy one: measured better only for long runs of the fp16 mode, whose calls
+ * are launch-latency chains (1228 against 1166 utterances/s in 200-utterance regions; 1134 against 1149 in the 20-utterance
+ * regions; f32: 289 against 294 / 296.6 both) — profiles/r06_queue_map.txt.  No reference
+ * counterpart (the reference has one model instance and Python threads: larynx/__init__.py:146-157). */
+int mi355tts_worker_queue_groups(mi355tts_ctx* ctx, int32_t* groups, int capacity);
 
 /* ---- single operators (kernel-level parity tests, drop-in conv) ------------- */
 /* y[B][Cout][L] = act_out(bias + conv1d(lrelu_slope(x[B][Cin][L]), w[Cout][Cin][K], dilation, "same" padding)) */

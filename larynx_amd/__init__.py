@@ -98,6 +98,18 @@ def sentence_task(text: str, phoneme_ids, audio_settings, tts_model, tts_setting
     return audio
 
 
+def _ensure_pool_workers(executor, *models):
+    """One worker per pool thread (+ a spare) on the models' engine before the first sentence is submitted: the engine then knows
+    which worker streams share a hardware queue and spreads the sentences' calls evenly (Engine.ensure_workers)."""
+    n = getattr(executor, "_max_workers", None)
+    if not isinstance(n, int) or n < 2:
+        return
+    for m in models:
+        eng = getattr(m, "engine", None)
+        if eng is not None and hasattr(eng, "ensure_workers"):
+            eng.ensure_workers(min(n, 32) + 1)
+
+
 def phonemes_to_speech(sentences: typing.Iterable[typing.Tuple[str, typing.Sequence[int]]], tts_model, vocoder_model,
                        tts_settings: typing.Optional[SettingsType] = None,
                        vocoder_settings: typing.Optional[SettingsType] = None,
@@ -107,6 +119,7 @@ def phonemes_to_speech(sentences: typing.Iterable[typing.Tuple[str, typing.Seque
     yielded in submission order."""
     own = executor is None
     executor = executor or ThreadPoolExecutor()
+    _ensure_pool_workers(executor, tts_model, vocoder_model)
     try:
         audio_settings = getattr(tts_model, "audio_settings", None)
         futures = []

@@ -120,6 +120,9 @@ struct Worker {
   // this worker's launches are neither profiled nor counted per kernel name (the dispatch self-check's own launches are not a
   // caller's: a worker-local switch, so concurrent calls on the context keep their samples and counts)
   bool quiet = false;
+  // hardware-queue group of `stream` (streams of one group run their kernels one after the other): learnt by
+  // probe_queue_groups at mi355tts_reserve, -1 = not probed (a worker created on demand)
+  int qgroup = -1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   // side streams for the independent MRF branches of a HiFi-GAN stage
   hipStream_t aux[2] = {nullptr, nullptr};
@@ -149,6 +152,9 @@ struct mi355tts_ctx {
   // calls currently holding a worker; with "adaptive_schedule" on and more than one in flight the vocoder
   // launches the members of a grouped step one by one (and never forks its MRF chains)
   std::atomic<int> active_calls{0};
+  // calls in flight per hardware-queue group (index = Worker::qgroup; guarded by `mu`): acquire_worker hands out the free worker
+  // whose group is the least busy
+  std::vector<int> qgroup_busy;
   std::atomic<bool> adaptive_schedule{false};
   std::atomic<int> gate16_wide{512};  // ... with two row tiles per workgroup in passes of at least this many 16-row tiles (0 = never; same bits)
   std::atomic<bool> gate16{true};     // GlowTTS WaveNet gate convs on 16-row tiles (gate16.h) when the launch is small
@@ -228,8 +234,27 @@ static int acquire_worker(mi355tts_ctx* ctx, Worker** out) {
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->free_workers.empty()) {
-      *out = ctx->free_workers.back();
-      ctx->free_workers.pop_back();
+      // the free worker whose hardware queue carries the fewest calls right now (ties, and workers that were never probed: the
+      // most recently released one, as before)
+      size_t pick = ctx->free_workers.size() - 1;
+      if (!ctx->qgroup_busy.empty()) {
+        // (MI355TTS_QUEUE_POLICY = 1, probe: an idle queue first, otherwise the BUSIEST one — exclusive queues for as many calls as
+        // there are queues, the rest piled on one)
+        static const int policy = [] { const char* e = std::getenv("MI355TTS_QUEUE_POLICY"); return e ? std::atoi(e) : 0; }();
+        int best = 1 << 30;
+        for (size_t i = ctx->free_workers.size(); i-- > 0;) {
+          const int g = ctx->free_workers[i]->qgroup;
+          int busy = (g >= 0 && g < (int)ctx->qgroup_busy.size()) ? ctx->qgroup_busy[g] : 0;
+          if (policy == 1 && busy > 0) busy = 1000 - busy;
+          if (busy < best) {
+            best = busy;
+            pick = i;
+          }
+        }
+      }
+      *out = ctx->free_workers[pick];
+      ctx->free_workers.erase(ctx->free_workers.begin() + (long)pick);
+      if ((*out)->qgroup >= 0 && (*out)->qgroup < (int)ctx->qgroup_busy.size()) ctx->qgroup_busy[(*out)->qgroup] += 1;
       (*out)->arena_pos = 0;
       (*out)->flop_scale = 1.0;
       snapshot_options(ctx, *out);
@@ -284,6 +309,7 @@ static void release_worker(mi355tts_ctx* ctx, Worker* w) {
   ctx->active_calls.fetch_sub(1, std::memory_order_relaxed);
   drain_profile(ctx, w);
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (w->qgroup >= 0 && w->qgroup < (int)ctx->qgroup_busy.size() && ctx->qgroup_busy[w->qgroup] > 0) ctx->qgroup_busy[w->qgroup] -= 1;
   ctx->free_workers.push_back(w);
 }
 

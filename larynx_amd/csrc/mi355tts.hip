@@ -987,6 +987,74 @@ extern "C" int mi355tts_synthesize_speakers(mi355tts_ctx* ctx, int glow, int voc
 // workspaces and the result-block pool for calls of up to `max_batch` rows x `max_ids`
 // ids x `max_frames` frames, so that steady-state calls never hipMalloc / hipFree (both
 // synchronise the whole device and stall every other in-flight call).
+// ---- which worker streams share a hardware queue (mi355tts_reserve)
+// The runtime deals its few hardware queues (4: GPU_MAX_HW_QUEUES) to streams when a stream is first used; two streams on one
+// queue run their kernels one after the other.  How it deals is not ours to know (measured: the nine workers of an 8-caller
+// context land 3 / 2 / 2 / 1 + spare on the four queues, or 2 / 2 / 2 / 2, depending on how many streams the host process used
+// before — rocprofv3 kernel trace, tools/gpu/queue_map.sh — and the driver's 20-utterance regions read 287.5 against 293
+// utterances/s: profiles/r06_queue_map.txt).  So the context MEASURES it once: stream A runs a kernel that waits for a host flag,
+// stream B a kernel that raises another; if B's flag does not come up while A waits, B sits behind A in A's queue.  acquire_worker
+// then hands out the free worker whose queue carries the fewest calls.  Which worker a call gets never changes its result.
+__global__ void queue_bind_kernel() {}
+__global__ void queue_wait_kernel(int* go, long long max_ticks) {
+  const long long t0 = wall_clock64();  // 100 MHz: the bound keeps a lost flag from hanging the queue
+  while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void queue_mark_kernel(int* done) { __hip_atomic_store(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// flags: two ints of host memory the device can reach ([0] = go, [1] = done)
+static bool streams_share_queue(hipStream_t a, hipStream_t b, int* flags) {
+  __atomic_store_n(&flags[0], 0, __ATOMIC_RELEASE);
+  __atomic_store_n(&flags[1], 0, __ATOMIC_RELEASE);
+  hipLaunchKernelGGL(queue_wait_kernel, dim3(1), dim3(1), 0, a, flags, 400000LL);  // at most 4 ms
+  hipLaunchKernelGGL(queue_mark_kernel, dim3(1), dim3(1), 0, b, flags + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = false;
+  while (!(seen = __atomic_load_n(&flags[1], __ATOMIC_ACQUIRE) != 0) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) {
+  }
+  __atomic_store_n(&flags[0], 1, __ATOMIC_RELEASE);
+  hipStreamSynchronize(a);
+  hipStreamSynchronize(b);
+  return !seen;
+}
+// groups the workers by hardware queue (Worker::qgroup) and sizes ctx->qgroup_busy; every worker in `ws` is held by the caller
+static void probe_queue_groups(mi355tts_ctx* ctx, const std::vector<Worker*>& ws) {
+  static const bool off = [] { const char* e = std::getenv("MI355TTS_NO_QUEUE_PROBE"); return e && std::atoi(e) != 0; }();
+  if (off || ws.size() < 2) return;
+  int* flags = nullptr;
+  if (hipHostMalloc(&flags, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return;  // fine-grained: the device sees the host's store while its kernel runs
+  // every main stream used once, back to back, before anything is measured: bound to its queue
+  for (Worker* w : ws) hipLaunchKernelGGL(queue_bind_kernel, dim3(1), dim3(64), 0, w->stream);
+  for (Worker* w : ws) hipStreamSynchronize(w->stream);
+  std::vector<Worker*> reps;
+  for (Worker* w : ws) {
+    int g = -1;
+    for (size_t r = 0; r < reps.size() && g < 0; ++r)
+      if (streams_share_queue(reps[r]->stream, w->stream, flags)) g = (int)r;
+    if (g < 0) {
+      g = (int)reps.size();
+      reps.push_back(w);
+    }
+    w->qgroup = g;
+  }
+  hipHostFree(flags);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (Worker* w : ctx->all_workers)  // a worker some other call holds right now was not probed: its old group number means nothing any more
+    if (std::find(ws.begin(), ws.end(), w) == ws.end()) w->qgroup = -1;
+  // (held workers were counted busy under their OLD groups, if any: the caller releases them after this, so start from zero
+  // and let release_worker's floor at 0 absorb them)
+  ctx->qgroup_busy.assign(reps.size(), 0);
+  for (Worker* w : ws) ctx->qgroup_busy[w->qgroup] += 1;  // they are held right now
+}
+
+extern "C" int mi355tts_worker_queue_groups(mi355tts_ctx* ctx, int32_t* groups, int capacity) {
+  if (!ctx || (capacity > 0 && !groups)) return fail(MI355TTS_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int n = (int)ctx->all_workers.size();
+  for (int i = 0; i < n && i < capacity; ++i) groups[i] = ctx->all_workers[i]->qgroup;
+  return n;
+}
+
 extern "C" int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vocoder, int max_batch, int max_ids,
                                 int max_frames, int denoiser, int max_pad_samples) {
   if (!ctx || workers < 1 || workers > 256 || max_batch < 1 || max_ids < 1 || max_frames < 1 || max_pad_samples < 0)
@@ -1037,6 +1105,7 @@ extern "C" int mi355tts_reserve(mi355tts_ctx* ctx, int workers, int glow, int vo
       if (!rc && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess) rc = fail(MI355TTS_ERR_HIP, "event creation failed");
     }
   }
+  if (!rc) probe_queue_groups(ctx, held);  // which workers share a hardware queue: acquire_worker spreads the calls over the queues
   for (Worker* w : held) release_worker(ctx, w);
   if (rc) return rc;
   // result blocks: per in-flight call two mel planes + one frame-count block (the pool must be able to hold them all)

@@ -317,6 +317,26 @@ class Engine:
         ffi.check(self.lib, self.lib.mi355tts_reserve(self._ctx, int(workers), int(glow), int(vocoder), int(max_batch), int(max_ids),
                                                      int(max_frames), 1 if denoiser else 0, int(max_pad_samples)))
 
+    def ensure_workers(self, n: int):
+        """At least `n` per-call workers exist and their streams' hardware queues are known (`mi355tts_reserve` without models: it
+        creates the workers, measures which of their streams share a hardware queue — calls are then spread evenly over the queues —
+        and leaves the workspaces to grow on first use).  Idempotent; the hosts of a sentence thread pool call it with the pool's
+        size + 1 (larynx/__init__.py:146-157: one `_sentence_task` per pool thread)."""
+        n = max(1, min(int(n), 64))
+        if n > getattr(self, "_ensured_workers", 0):
+            self.reserve(n, 0, 0, max_batch=1, max_ids=1, max_frames=1)
+            self._ensured_workers = n
+
+    def worker_queue_groups(self) -> typing.List[int]:
+        """The hardware-queue group of every worker, in creation order (`mi355tts_worker_queue_groups`; -1 = not probed)."""
+        import ctypes
+
+        buf = (ctypes.c_int32 * 256)()
+        n = self.lib.mi355tts_worker_queue_groups(self._ctx, buf, 256)
+        if n < 0:
+            ffi.check(self.lib, n)
+        return [int(buf[i]) for i in range(min(n, 256))]
+
     def mel_from_numpy(self, mel: np.ndarray, frames=None, audio_settings=None) -> MelBatch:
         mel = np.ascontiguousarray(mel, np.float32)
         if mel.ndim == 2:

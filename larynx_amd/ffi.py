@@ -132,6 +132,7 @@ _SIGNATURES: typing.Dict[str, typing.Tuple[typing.Any, typing.List[typing.Any]]]
          C.c_int64, C.c_uint32],
     ),
     "mi355tts_reserve": (C.c_int, [_VP] + [C.c_int] * 8),
+    "mi355tts_worker_queue_groups": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int]),
     "mi355tts_op_gauss_noise": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_int, C.c_int, _VP]),
     "mi355tts_op_denoise": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP, C.c_float, _VP]),
     "mi355tts_op_conv1d": (

@@ -65,6 +65,10 @@ def stream_raw_pcm(sentences: typing.Iterable[Sentence], tts_model, vocoder_mode
     wt = threading.Thread(target=writer, daemon=True)
     wt.start()
     pending: typing.Deque = collections.deque()
+    for m in (tts_model, vocoder_model):  # a worker per pool thread (+ a spare) up front: calls spread evenly over the hardware queues
+        eng = getattr(m, "engine", None)
+        if eng is not None and hasattr(eng, "ensure_workers") and max_thread_workers and max_thread_workers >= 2:
+            eng.ensure_workers(int(max_thread_workers) + 1)
     try:
         with ThreadPoolExecutor(max_workers=max_thread_workers) as pool:
 

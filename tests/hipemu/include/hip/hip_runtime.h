@@ -44,7 +44,7 @@ enum hipMemcpyKind {
   hipMemcpyDeviceToDevice = 3,
   hipMemcpyDefault = 4
 };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventBlockingSync = 1 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000, hipEventDisableTiming = 2, hipEventBlockingSync = 1 };
 
 struct dim3 {
   unsigned x, y, z;
@@ -316,6 +316,13 @@ inline u32x2_emu permlane32_swap(uint32_t old_v, uint32_t src_v) {
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 // only ever applied to wave-uniform values in csrc/ (it tells the compiler they ARE uniform)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// launches run to completion inside the launch call here: a kernel that waits for the host (mi355tts.hip, queue_wait_kernel) must
+// fall through at once — the clock leaps past any bound
+static inline long long wall_clock64() { static std::atomic<long long> t{0}; return t.fetch_add(1LL << 40); }
+#define __HIP_MEMORY_SCOPE_SYSTEM 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 

@@ -117,6 +117,14 @@ def test_reserve_then_calls_do_not_grow(emu_engine, tiny):
     a = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0)[2]
     b = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0)[2]
     assert np.array_equal(a, b)
+    # mi355tts_reserve also measured which worker streams share a hardware queue (mi355tts_worker_queue_groups); on the emulator a
+    # launch completes inside the launch call, so no stream ever waits behind another: every probed worker is a group of its own,
+    # the groups are numbered 0 .. n - 1, and calls keep working (the free worker of the least busy group is taken)
+    groups = emu_engine.worker_queue_groups()
+    probed = [g for g in groups if g >= 0]
+    assert len(groups) >= 3 and len(probed) >= 3 and sorted(probed) == list(range(len(probed))), groups
+    c = emu_engine.synthesize(tiny["g"], tiny["v"], ids, 0.0, 1.0)[2]
+    assert np.array_equal(a, c)
 
 
 def check_schedule_invariance(eng, v, num_mels, frames=33, threads=4):

@@ -450,6 +450,42 @@ def test_busy_context_takes_128_column_tiles(gpu_engine):
         np.testing.assert_array_equal(w, lone)
 
 
+def test_worker_streams_are_grouped_by_hardware_queue(gpu_engine):
+    """`mi355tts_reserve` measures which worker streams share a hardware queue (the runtime has 4 — GPU_MAX_HW_QUEUES — and deals
+    them to streams as they are first used; two streams of one queue run their kernels one after the other) and a call takes the
+    free worker whose queue carries the fewest calls.  With 9 workers: every worker probed, between 2 and 8 groups numbered from
+    0, no group empty, and at least one group with two streams (9 streams cannot have 4 queues to themselves).  Results do not
+    depend on which worker a call gets: eight concurrent callers, every waveform equal to the lone call's."""
+    import threading
+
+    vhp = HP.VOCODER_QUALITY["medium"]
+    _, (vsd, v) = models(gpu_engine, HP.LJSPEECH, vhp)
+    gpu_engine.reserve(9, 0, v, max_batch=1, max_frames=256)
+    groups = gpu_engine.worker_queue_groups()
+    probed = [g for g in groups if g >= 0]
+    assert len(probed) >= 9, groups
+    n = max(probed) + 1
+    assert 2 <= n <= 8 and set(probed) == set(range(n)), groups
+    assert max(probed.count(g) for g in range(n)) >= 2, groups
+    mel = (0.57 + 0.06 * np.random.default_rng(6).standard_normal((1, 80, 200))).astype(np.float32)
+    lone, _ = gpu_engine.hifigan_infer(v, gpu_engine.mel_from_numpy(mel[0]))
+    out, errs = [None] * 24, []
+
+    def work(t):
+        try:
+            for i in range(t, len(out), 8):
+                out[i], _ = gpu_engine.hifigan_infer(v, gpu_engine.mel_from_numpy(mel[0]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for w in out:
+        np.testing.assert_array_equal(w, lone)
+
+
 def test_dispatch_order_selfcheck_on_the_device(gpu_engine):
     """`mi355tts_dispatch_selfcheck`: the dispatcher rule behind the snake order of fully resident grouped launches (and the
     promotion of the 256-channel stage that relies on it) is MEASURED on the device the library runs on — on an MI355X the snake
