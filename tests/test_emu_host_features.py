@@ -520,7 +520,7 @@ def test_grouped_launch_promotion_and_snake_order(emu_engine, monkeypatch):
         assert not np.array_equal(small, promoted) and np.abs(small - promoted).max() <= 1e-6  # the k-split tile sums in another order
         assert np.array_equal(unpromoted, small)
         # the rule: a step just above one workgroup per CU stays on the small tiles — 6 tiles per member on "16 CUs" would put
-        # 11 + 3 tap-units on six CUs where the mean is 7.9 (group_order_imbalance 1.78 > 1.25)
+        # 11 + 3 tap-units on six CUs where the mean is 7.9 (group_order_imbalance 1.78 > 1.35)
         mel2 = (0.5 + 0.1 * rng.standard_normal((1, hp.num_mels, 170))).astype(np.float32)
         mb2 = emu_engine.mel_from_numpy(mel2)
         small2, _ = emu_engine.hifigan_infer(v, mb2)           # MI355TTS_GROUP_NCU = 1024: nothing promoted
