@@ -134,6 +134,15 @@ def test_phonemes_to_speech_keeps_submission_order(emu_library, voice_dirs):
     for (text, ids), r in zip(sents, res):
         one = voc.mels_to_audio(tts.phonemes_to_mels(ids, {"noise_scale": 0.0}))
         assert np.array_equal(one, r.audio)
+    # the pool host asked the engine for a worker per pool thread (+ a spare) before the first sentence (Engine.ensure_workers:
+    # mi355tts_reserve without models), so the engine knows its worker streams' hardware-queue groups; an explicit pool of three:
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        res3 = list(larynx_amd.phonemes_to_speech(sents, tts, voc, tts_settings={"noise_scale": 0.0}, executor=pool))
+    groups = tts.engine.worker_queue_groups()
+    assert len(groups) >= 4 and sum(1 for g in groups if g >= 0) >= 4, groups
+    assert all(np.array_equal(a.audio, b.audio) for a, b in zip(res, res3))
 
 
 def test_raw_stream_writes_sentences_in_order(emu_library, voice_dirs):
